@@ -1,0 +1,1838 @@
+/*
+ * ellp_oracle.c — CPU oracle (TEST INFRASTRUCTURE, see ellp_oracle.h).
+ *
+ * Plain-C restatement of kehlert/ellp 0.2.0.  File:line citations are relative to the
+ * reference tree.  Single-threaded on purpose: nalgebra, which carries all of the
+ * reference's arithmetic, is single-threaded.
+ *
+ * Build with -ffp-contract=off: Rust never contracts a*b+c into an FMA.
+ */
+#include "ellp_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EPS EO_EPS
+
+/* ------------------------------------------------------------------ utilities */
+
+static void *xmalloc(size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (!p) {
+        fprintf(stderr, "ellp_oracle: out of memory (%zu bytes)\n", n);
+        abort();
+    }
+    return p;
+}
+static void *xcalloc(size_t n, size_t s) {
+    void *p = calloc(n ? n : 1, s ? s : 1);
+    if (!p) {
+        fprintf(stderr, "ellp_oracle: out of memory\n");
+        abort();
+    }
+    return p;
+}
+static double *dcopy(const double *s, int64_t n) {
+    double *d = (double *)xmalloc(sizeof(double) * (size_t)n);
+    if (n) memcpy(d, s, sizeof(double) * (size_t)n);
+    return d;
+}
+static int64_t *icopy(const int64_t *s, int64_t n) {
+    int64_t *d = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)n);
+    if (n) memcpy(d, s, sizeof(int64_t) * (size_t)n);
+    return d;
+}
+static uint8_t *bcopy8(const uint8_t *s, int64_t n) {
+    uint8_t *d = (uint8_t *)xmalloc((size_t)n);
+    if (n) memcpy(d, s, (size_t)n);
+    return d;
+}
+static void set_err(char *err, size_t errlen, const char *msg) {
+    if (err && errlen) {
+        snprintf(err, errlen, "%s", msg);
+    }
+}
+
+static eo_trace_fn g_trace = NULL;
+static void *g_trace_user = NULL;
+void eo_set_trace(eo_trace_fn fn, void *user) {
+    g_trace = fn;
+    g_trace_user = user;
+}
+
+/* f64::signum (Rust): 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN */
+static double rust_signum(double v) {
+    if (isnan(v)) return v;
+    return signbit(v) ? -1.0 : 1.0;
+}
+
+/* ------------------------------------------------------------------ permutation sequences
+ * nalgebra PermutationSequence: a list of row transpositions (i, j).
+ * permute_rows applies them in recording order, inv_permute_rows in reverse order. */
+typedef struct {
+    int64_t len;
+    int64_t *a, *b;
+} perm_t;
+
+static void perm_init(perm_t *p, int64_t cap) {
+    p->len = 0;
+    p->a = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(cap > 0 ? cap : 1));
+    p->b = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(cap > 0 ? cap : 1));
+}
+static void perm_free(perm_t *p) {
+    free(p->a);
+    free(p->b);
+    p->a = p->b = NULL;
+    p->len = 0;
+}
+static void perm_push(perm_t *p, int64_t i, int64_t j) {
+    p->a[p->len] = i;
+    p->b[p->len] = j;
+    p->len++;
+}
+static void perm_rows_d(const perm_t *p, double *v) {
+    for (int64_t k = 0; k < p->len; ++k) {
+        double t = v[p->a[k]];
+        v[p->a[k]] = v[p->b[k]];
+        v[p->b[k]] = t;
+    }
+}
+static void inv_perm_rows_d(const perm_t *p, double *v) {
+    for (int64_t k = p->len - 1; k >= 0; --k) {
+        double t = v[p->a[k]];
+        v[p->a[k]] = v[p->b[k]];
+        v[p->b[k]] = t;
+    }
+}
+static void perm_rows_i(const perm_t *p, int64_t *v) {
+    for (int64_t k = 0; k < p->len; ++k) {
+        int64_t t = v[p->a[k]];
+        v[p->a[k]] = v[p->b[k]];
+        v[p->b[k]] = t;
+    }
+}
+
+/* ------------------------------------------------------------------ LU (nalgebra linalg::LU)
+ * Partial (row) pivoting, P*A = L*U, unit-diagonal L stored below the diagonal of `lu`.
+ * Pivot = FIRST entry of maximal |.| in the column (iamax uses a strict '>').
+ * A zero pivot column is skipped (no elimination), as nalgebra does. */
+typedef struct {
+    int64_t nr, nc;
+    double *lu; /* nr x nc, col-major, ld = nr */
+    perm_t p;
+} lu_t;
+
+static void lu_free(lu_t *f) {
+    free(f->lu);
+    f->lu = NULL;
+    perm_free(&f->p);
+}
+
+/* gauss_step / gauss_step_swap: multipliers are a * (1/diag) (two roundings), the trailing
+ * update is down[:,k] += (-pivot_row[k]) * coeffs (mul then add). */
+static void lu_factor_inplace(lu_t *f) {
+    const int64_t nr = f->nr, nc = f->nc;
+    const int64_t mn = nr < nc ? nr : nc;
+    double *M = f->lu;
+    for (int64_t i = 0; i < mn; ++i) {
+        double *ci = M + i * nr;
+        int64_t piv = i;
+        double best = fabs(ci[i]);
+        for (int64_t r = i + 1; r < nr; ++r) {
+            double v = fabs(ci[r]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        double diag = ci[piv];
+        if (diag == 0.0) continue;
+        if (piv != i) {
+            perm_push(&f->p, i, piv);
+            /* swap rows i, piv in columns [0, i) and in column i .. nc (gauss_step_swap) */
+            for (int64_t k = 0; k < nc; ++k) {
+                double *ck = M + k * nr;
+                double t = ck[i];
+                ck[i] = ck[piv];
+                ck[piv] = t;
+            }
+        }
+        double inv_diag = 1.0 / diag;
+        for (int64_t r = i + 1; r < nr; ++r) ci[r] *= inv_diag;
+        for (int64_t k = i + 1; k < nc; ++k) {
+            double *ck = M + k * nr;
+            double a = -ck[i];
+            if (a == 0.0) {
+                /* a*x + y with a == -0.0/0.0 leaves y unchanged except for signed zeros;
+                 * skipping is value-identical for finite data and keeps big sparse-ish
+                 * bases (slack/artificial columns) fast. */
+                continue;
+            }
+            for (int64_t r = i + 1; r < nr; ++r) ck[r] = a * ci[r] + ck[r];
+        }
+    }
+}
+
+static void lu_factor(lu_t *f, const double *A, int64_t nr, int64_t nc) {
+    f->nr = nr;
+    f->nc = nc;
+    f->lu = dcopy(A, nr * nc);
+    perm_init(&f->p, (nr < nc ? nr : nc) + 1);
+    lu_factor_inplace(f);
+}
+
+/* any |U_ii| < EPS over the min(nr,nc) diagonal */
+static int lu_small_diag(const lu_t *f) {
+    int64_t mn = f->nr < f->nc ? f->nr : f->nc;
+    for (int64_t i = 0; i < mn; ++i)
+        if (fabs(f->lu[i + i * f->nr]) < EPS) return 1;
+    return 0;
+}
+
+/* U^T x = b  (tr_solve_upper_triangular): x_i = (b_i - U[0..i,i].x[0..i]) / U_ii */
+static int lu_tr_solve_upper(const lu_t *f, double *b) {
+    const int64_t n = f->nr;
+    for (int64_t i = 0; i < n; ++i) {
+        const double *ci = f->lu + i * n;
+        double dot = 0.0;
+        for (int64_t k = 0; k < i; ++k) dot += ci[k] * b[k];
+        b[i] -= dot;
+        double diag = ci[i];
+        if (diag == 0.0) return 0;
+        b[i] /= diag;
+    }
+    return 1;
+}
+/* L^T x = b, unit diagonal (tr_solve_lower_triangular on l()) */
+static int lu_tr_solve_lower_unit(const lu_t *f, double *b) {
+    const int64_t n = f->nr;
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const double *ci = f->lu + i * n;
+        double dot = 0.0;
+        for (int64_t k = i + 1; k < n; ++k) dot += ci[k] * b[k];
+        b[i] -= dot;
+        b[i] /= 1.0;
+    }
+    return 1;
+}
+/* LU::solve: x = P b ; L y = x (column-oriented, unit diag) ; U z = y (column-oriented) */
+static int lu_solve(const lu_t *f, double *b) {
+    const int64_t n = f->nr;
+    perm_rows_d(&f->p, b);
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        double coeff = b[i];
+        if (coeff == 0.0) continue;
+        const double *ci = f->lu + i * n;
+        double a = -coeff;
+        for (int64_t r = i + 1; r < n; ++r) b[r] = a * ci[r] + b[r];
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+        const double *ci = f->lu + i * n;
+        double diag = ci[i];
+        if (diag == 0.0) return 0;
+        double coeff = b[i] / diag;
+        b[i] = coeff;
+        if (coeff == 0.0) continue;
+        double a = -coeff;
+        for (int64_t r = 0; r < i; ++r) b[r] = a * ci[r] + b[r];
+    }
+    return 1;
+}
+/* u = A_B^{-T} c_B :  U^T ut = c ; L^T w = ut ; u = P^{-1} w  (primal…:184-187) */
+static int lu_btran(const lu_t *f, double *v) {
+    if (!lu_tr_solve_upper(f, v)) return 0;
+    if (!lu_tr_solve_lower_unit(f, v)) return 0;
+    inv_perm_rows_d(&f->p, v);
+    return 1;
+}
+
+/* ------------------------------------------------------------------ Problem (problem.rs) */
+
+typedef struct {
+    int64_t id;
+    double obj;
+    int kind;
+    double lb, ub;
+} var_t;
+typedef struct {
+    int64_t n;
+    int64_t *ids;
+    double *coef;
+    int op;
+    double rhs;
+} con_t;
+
+struct eo_problem {
+    var_t *vars;
+    int64_t nvars, capv;
+    con_t *cons;
+    int64_t ncons, capc;
+    uint8_t *idset; /* idset[id] = 1 if used */
+    int64_t idcap;
+};
+
+eo_problem *eo_problem_new(void) { return (eo_problem *)xcalloc(1, sizeof(eo_problem)); }
+
+void eo_problem_free(eo_problem *p) {
+    if (!p) return;
+    for (int64_t i = 0; i < p->ncons; ++i) {
+        free(p->cons[i].ids);
+        free(p->cons[i].coef);
+    }
+    free(p->cons);
+    free(p->vars);
+    free(p->idset);
+    free(p);
+}
+
+int64_t eo_num_vars(const eo_problem *p) { return p->nvars; }
+int64_t eo_num_constraints(const eo_problem *p) { return p->ncons; }
+
+/* problem.rs:35-83 */
+int64_t eo_add_var_with_id(eo_problem *p, double obj, int kind, double lb, double ub, int64_t id) {
+    if (id < 0) return -1;
+    switch (kind) {
+    case EO_FREE: break;
+    case EO_LOWER:
+        if (!isfinite(lb)) return -1;
+        break;
+    case EO_UPPER:
+        if (!isfinite(ub)) return -1;
+        break;
+    case EO_TWOSIDED:
+        if (lb > ub) return -1;
+        if (!isfinite(lb) || !isfinite(ub)) return -1;
+        break;
+    case EO_FIXED:
+        if (!isfinite(lb)) return -1;
+        ub = lb;
+        break;
+    default: return -1;
+    }
+    if (id >= p->idcap) {
+        int64_t nc = p->idcap ? p->idcap : 64;
+        while (nc <= id) nc *= 2;
+        p->idset = (uint8_t *)realloc(p->idset, (size_t)nc);
+        memset(p->idset + p->idcap, 0, (size_t)(nc - p->idcap));
+        p->idcap = nc;
+    }
+    if (p->idset[id]) return -1;
+    p->idset[id] = 1;
+    if (p->nvars == p->capv) {
+        p->capv = p->capv ? 2 * p->capv : 64;
+        p->vars = (var_t *)realloc(p->vars, sizeof(var_t) * (size_t)p->capv);
+    }
+    var_t *v = &p->vars[p->nvars++];
+    v->id = id;
+    v->obj = obj;
+    v->kind = kind;
+    v->lb = lb;
+    v->ub = ub;
+    return id;
+}
+/* problem.rs:24-33 */
+int64_t eo_add_var(eo_problem *p, double obj, int kind, double lb, double ub) {
+    return eo_add_var_with_id(p, obj, kind, lb, ub, p->nvars);
+}
+/* problem.rs:85-106 */
+int eo_add_constraint(eo_problem *p, int64_t n, const int64_t *ids, const double *coef, int op,
+                      double rhs) {
+    for (int64_t k = 0; k < n; ++k) {
+        if (ids[k] < 0 || ids[k] >= p->idcap || !p->idset[ids[k]]) return -1;
+    }
+    if (p->ncons == p->capc) {
+        p->capc = p->capc ? 2 * p->capc : 64;
+        p->cons = (con_t *)realloc(p->cons, sizeof(con_t) * (size_t)p->capc);
+    }
+    con_t *c = &p->cons[p->ncons++];
+    c->n = n;
+    c->ids = icopy(ids, n);
+    c->coef = dcopy(coef, n);
+    c->op = op;
+    c->rhs = rhs;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ phases */
+
+static eo_phase *phase_alloc(int64_t m, int64_t n, int64_t n_c) {
+    eo_phase *ph = (eo_phase *)xcalloc(1, sizeof(eo_phase));
+    ph->m = m;
+    ph->n = n;
+    ph->n_c = n_c;
+    ph->A = (double *)xcalloc((size_t)(m * n), sizeof(double));
+    ph->c = (double *)xcalloc((size_t)n_c, sizeof(double));
+    ph->b = (double *)xcalloc((size_t)m, sizeof(double));
+    ph->kind = (uint8_t *)xcalloc((size_t)n_c, 1);
+    ph->lb = (double *)xcalloc((size_t)n_c, sizeof(double));
+    ph->ub = (double *)xcalloc((size_t)n_c, sizeof(double));
+    ph->x = (double *)xcalloc((size_t)n_c, sizeof(double));
+    ph->B = (int64_t *)xcalloc((size_t)(n_c + m + 1), sizeof(int64_t));
+    ph->N = (int64_t *)xcalloc((size_t)(n_c + m + 1), sizeof(int64_t));
+    ph->Nb = (uint8_t *)xcalloc((size_t)(n_c + m + 1), 1);
+    return ph;
+}
+
+void eo_phase_free(eo_phase *ph) {
+    if (!ph) return;
+    free(ph->A);
+    free(ph->c);
+    free(ph->b);
+    free(ph->kind);
+    free(ph->lb);
+    free(ph->ub);
+    free(ph->x);
+    free(ph->B);
+    free(ph->N);
+    free(ph->Nb);
+    free(ph->y);
+    free(ph->d);
+    free(ph->orig_obj);
+    free(ph->orig_kind);
+    free(ph->orig_lb);
+    free(ph->orig_ub);
+    free(ph->p1vars);
+    free(ph->p1ids);
+    if (ph->orig) eo_phase_free(ph->orig);
+    free(ph);
+}
+
+static void phase_keep_orig(eo_phase *ph, const eo_problem *p) {
+    ph->n_orig_vars = p->nvars;
+    ph->orig_obj = (double *)xmalloc(sizeof(double) * (size_t)p->nvars);
+    ph->orig_kind = (uint8_t *)xmalloc((size_t)p->nvars);
+    ph->orig_lb = (double *)xmalloc(sizeof(double) * (size_t)p->nvars);
+    ph->orig_ub = (double *)xmalloc(sizeof(double) * (size_t)p->nvars);
+    for (int64_t i = 0; i < p->nvars; ++i) {
+        ph->orig_obj[i] = p->vars[i].obj;
+        ph->orig_kind[i] = (uint8_t)p->vars[i].kind;
+        ph->orig_lb[i] = p->vars[i].lb;
+        ph->orig_ub[i] = p->vars[i].ub;
+    }
+}
+static void phase_copy_orig(eo_phase *dst, const eo_phase *src) {
+    dst->n_orig_vars = src->n_orig_vars;
+    dst->orig_obj = dcopy(src->orig_obj, src->n_orig_vars);
+    dst->orig_kind = bcopy8(src->orig_kind, src->n_orig_vars);
+    dst->orig_lb = dcopy(src->orig_lb, src->n_orig_vars);
+    dst->orig_ub = dcopy(src->orig_ub, src->n_orig_vars);
+}
+
+/* standard_form.rs:48 */
+double eo_phase_obj(const eo_phase *ph) {
+    double s = 0.0;
+    for (int64_t i = 0; i < ph->n_c; ++i) s += ph->c[i] * ph->x[i];
+    return s;
+}
+/* standard_form.rs:52-68 */
+static double dual_obj(int64_t m, int64_t n_c, const double *b, const uint8_t *kind,
+                       const double *lb, const double *ub, const double *y, const double *d) {
+    double obj = 0.0;
+    for (int64_t i = 0; i < m; ++i) obj += b[i] * y[i];
+    for (int64_t i = 0; i < n_c; ++i) {
+        switch (kind[i]) {
+        case EO_FREE: break;
+        case EO_LOWER: obj += lb[i] * d[i]; break;
+        case EO_UPPER: obj += ub[i] * d[i]; break;
+        case EO_TWOSIDED: obj += (d[i] > 0.0) ? lb[i] * d[i] : ub[i] * d[i]; break;
+        case EO_FIXED: obj += lb[i] * d[i]; break;
+        }
+    }
+    return obj;
+}
+double eo_phase_dual_obj(const eo_phase *ph) {
+    if (!ph->y || !ph->d) return NAN;
+    return dual_obj(ph->m, ph->n_c, ph->b, ph->kind, ph->lb, ph->ub, ph->y, ph->d);
+}
+
+/* ------------------------------------------------------------------ StandardForm
+ * standard_form.rs:78-191.  Returns a phase without a point (nB = nN = 0), or NULL if None. */
+
+/* Column-pivoted Householder QR of M (nr x nc, col-major, destroyed), nalgebra ColPivQR:
+ * at step i the pivot column is the column holding the entry of maximal |.| of the
+ * trailing block (icamax_full: column-major scan, strict '>'), not the largest-norm column.
+ * Outputs the swap sequence and |R_ii|. */
+static void col_piv_qr(double *M, int64_t nr, int64_t nc, perm_t *p, double *rdiag) {
+    const int64_t mn = nr < nc ? nr : nc;
+    for (int64_t i = 0; i < mn; ++i) {
+        int64_t pj = i;
+        double best = fabs(M[i + i * nr]);
+        for (int64_t j = i; j < nc; ++j) {
+            const double *cj = M + j * nr;
+            for (int64_t r = i; r < nr; ++r) {
+                double v = fabs(cj[r]);
+                if (v > best) {
+                    best = v;
+                    pj = j;
+                }
+            }
+        }
+        if (pj != i) {
+            double *a = M + i * nr, *b = M + pj * nr;
+            for (int64_t r = 0; r < nr; ++r) {
+                double t = a[r];
+                a[r] = b[r];
+                b[r] = t;
+            }
+        }
+        perm_push(p, i, pj);
+        /* householder::reflection_axis_mut on M[i.., i] */
+        double *v = M + i + i * nr;
+        const int64_t len = nr - i;
+        double sqn = 0.0;
+        for (int64_t r = 0; r < len; ++r) sqn += v[r] * v[r];
+        double norm = sqrt(sqn);
+        double modulus = fabs(v[0]);
+        double sign = (v[0] < 0.0) ? -1.0 : 1.0;
+        double signed_norm = sign * norm;
+        double factor = (sqn + modulus * norm) * 2.0;
+        v[0] += signed_norm;
+        if (factor != 0.0) {
+            double sf = sqrt(factor);
+            for (int64_t r = 0; r < len; ++r) v[r] /= sf;
+            double n2 = 0.0;
+            for (int64_t r = 0; r < len; ++r) n2 += v[r] * v[r];
+            n2 = sqrt(n2);
+            if (n2 != 0.0)
+                for (int64_t r = 0; r < len; ++r) v[r] /= n2;
+            rdiag[i] = fabs(signed_norm);
+            /* reflect the trailing columns: col -= 2 (v.col) v  (overall sign immaterial:
+             * only |entries| steer later pivots and only |R_ii| is consumed) */
+            for (int64_t j = i + 1; j < nc; ++j) {
+                double *cj = M + i + j * nr;
+                double dot = 0.0;
+                for (int64_t r = 0; r < len; ++r) dot += v[r] * cj[r];
+                double f2 = -2.0 * dot;
+                for (int64_t r = 0; r < len; ++r) cj[r] = f2 * v[r] + cj[r];
+            }
+        } else {
+            rdiag[i] = fabs(signed_norm);
+        }
+    }
+}
+
+static eo_phase *standard_form(const eo_problem *prob) {
+    const int64_t n = prob->nvars;
+    const int64_t m = prob->ncons;
+    int64_t num_slack = 0;
+    for (int64_t i = 0; i < m; ++i)
+        if (prob->cons[i].op != EO_EQ) num_slack++;
+    const int64_t tv = n + num_slack;
+
+    double *A = (double *)xcalloc((size_t)(m * tv), sizeof(double)); /* m x tv, ld m */
+    double *b = (double *)xcalloc((size_t)m, sizeof(double));
+    double *c = (double *)xcalloc((size_t)tv, sizeof(double));
+    uint8_t *kind = (uint8_t *)xmalloc((size_t)tv);
+    double *lb = (double *)xcalloc((size_t)tv, sizeof(double));
+    double *ub = (double *)xcalloc((size_t)tv, sizeof(double));
+    for (int64_t i = 0; i < tv; ++i) kind[i] = EO_LOWER; /* Lower(0.) default :106 */
+
+    int64_t maxid = -1;
+    for (int64_t i = 0; i < n; ++i)
+        if (prob->vars[i].id > maxid) maxid = prob->vars[i].id;
+    int64_t *id_to_index = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(maxid + 2));
+    for (int64_t i = 0; i < n; ++i) {
+        c[i] = prob->vars[i].obj;
+        kind[i] = (uint8_t)prob->vars[i].kind;
+        lb[i] = prob->vars[i].lb;
+        ub[i] = prob->vars[i].ub;
+        id_to_index[prob->vars[i].id] = i;
+    }
+
+    int64_t cur_slack_col = tv > 0 ? tv - 1 : 0; /* saturating_sub :115 */
+    int infeasible = 0;
+    for (int64_t i = 0; i < m && !infeasible; ++i) {
+        const con_t *cn = &prob->cons[i];
+        b[i] = cn->rhs;
+        if (cn->n == 0 && b[i] != 0.0) {
+            infeasible = 1;
+            break;
+        }
+        for (int64_t k = 0; k < cn->n; ++k) A[i + id_to_index[cn->ids[k]] * m] = cn->coef[k];
+        if (cn->op != EO_EQ) {
+            A[i + cur_slack_col * m] = (cn->op == EO_LTE) ? 1.0 : -1.0;
+            cur_slack_col -= 1;
+        }
+    }
+    free(id_to_index);
+    if (infeasible) {
+        free(A); free(b); free(c); free(kind); free(lb); free(ub);
+        return NULL;
+    }
+
+    /* remove redundant rows: A^T.col_piv_qr()  :142-181 */
+    const int64_t mn = tv < m ? tv : m;
+    double *At = (double *)xmalloc(sizeof(double) * (size_t)(tv * m + 1)); /* tv x m */
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < tv; ++j) At[j + i * tv] = A[i + j * m];
+    perm_t p;
+    perm_init(&p, mn + 1);
+    double *rdiag = (double *)xcalloc((size_t)(mn + 1), sizeof(double));
+    col_piv_qr(At, tv, m, &p, rdiag);
+    free(At);
+
+    inv_perm_rows_d(&p, b);
+    for (int64_t i = 0; i < mn; ++i)
+        if (fabs(rdiag[i]) < EPS) rdiag[i] = 0.0;
+    const int r_nonempty = (mn > 0 && m > 0);
+    const int is_trivial = r_nonempty && fabs(rdiag[0]) < EPS && fabs(b[0]) < EPS;
+    if (!is_trivial) {
+        /* R.tr_solve_upper_triangular(&b)? : fails iff a diagonal entry is exactly zero */
+        for (int64_t i = 0; i < mn; ++i) {
+            if (rdiag[i] == 0.0) {
+                infeasible = 1;
+                break;
+            }
+        }
+    }
+    perm_rows_d(&p, b);
+    if (infeasible) {
+        perm_free(&p);
+        free(rdiag); free(A); free(b); free(c); free(kind); free(lb); free(ub);
+        return NULL;
+    }
+    int64_t num_indep = mn;
+    for (int64_t i = 0; i < mn; ++i) {
+        if (fabs(rdiag[i]) < EPS) {
+            num_indep = i;
+            break;
+        }
+    }
+    int64_t *rows = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(m + 1));
+    for (int64_t i = 0; i < m; ++i) rows[i] = i;
+    perm_rows_i(&p, rows);
+    perm_free(&p);
+    free(rdiag);
+
+    eo_phase *sf = phase_alloc(num_indep, tv, tv);
+    for (int64_t k = 0; k < num_indep; ++k) {
+        const int64_t src = rows[k];
+        for (int64_t j = 0; j < tv; ++j) sf->A[k + j * num_indep] = A[src + j * m];
+        sf->b[k] = b[src];
+    }
+    memcpy(sf->c, c, sizeof(double) * (size_t)tv);
+    memcpy(sf->kind, kind, (size_t)tv);
+    memcpy(sf->lb, lb, sizeof(double) * (size_t)tv);
+    memcpy(sf->ub, ub, sizeof(double) * (size_t)tv);
+    phase_keep_orig(sf, prob);
+    free(rows); free(A); free(b); free(c); free(kind); free(lb); free(ub);
+    return sf;
+}
+
+/* ------------------------------------------------------------------ full-pivot LU (nalgebra FullPivLU) */
+typedef struct {
+    int64_t nr, nc;
+    double *lu;
+    perm_t p, q;
+} fplu_t;
+
+static void fplu_factor(fplu_t *f, const double *A, int64_t nr, int64_t nc) {
+    f->nr = nr;
+    f->nc = nc;
+    f->lu = dcopy(A, nr * nc);
+    const int64_t mn = nr < nc ? nr : nc;
+    perm_init(&f->p, mn + 1);
+    perm_init(&f->q, mn + 1);
+    double *M = f->lu;
+    for (int64_t i = 0; i < mn; ++i) {
+        int64_t pr = i, pc = i;
+        double best = fabs(M[i + i * nr]);
+        for (int64_t j = i; j < nc; ++j) {
+            for (int64_t r = i; r < nr; ++r) {
+                double v = fabs(M[r + j * nr]);
+                if (v > best) {
+                    best = v;
+                    pr = r;
+                    pc = j;
+                }
+            }
+        }
+        double diag = M[pr + pc * nr];
+        if (diag == 0.0) break;
+        if (pc != i) {
+            double *a = M + i * nr, *b = M + pc * nr;
+            for (int64_t r = 0; r < nr; ++r) {
+                double t = a[r];
+                a[r] = b[r];
+                b[r] = t;
+            }
+        }
+        perm_push(&f->q, i, pc);
+        if (pr != i) {
+            perm_push(&f->p, i, pr);
+            for (int64_t k = 0; k < nc; ++k) {
+                double t = M[i + k * nr];
+                M[i + k * nr] = M[pr + k * nr];
+                M[pr + k * nr] = t;
+            }
+        }
+        double *ci = M + i * nr;
+        double inv_diag = 1.0 / diag;
+        for (int64_t r = i + 1; r < nr; ++r) ci[r] *= inv_diag;
+        for (int64_t k = i + 1; k < nc; ++k) {
+            double *ck = M + k * nr;
+            double a = -ck[i];
+            for (int64_t r = i + 1; r < nr; ++r) ck[r] = a * ci[r] + ck[r];
+        }
+    }
+}
+static void fplu_free(fplu_t *f) {
+    free(f->lu);
+    perm_free(&f->p);
+    perm_free(&f->q);
+}
+
+/* ------------------------------------------------------------------ PrimalPhase1  (primal_problem.rs:80-261) */
+
+static void matvec_sub(const double *A, int64_t m, int64_t n, const double *v, const double *b,
+                       double *out) {
+    /* out = b - A v  (A*v accumulated column by column as nalgebra's gemv does) */
+    double *Av = (double *)xcalloc((size_t)m, sizeof(double));
+    for (int64_t j = 0; j < n; ++j) {
+        double vj = v[j];
+        if (vj == 0.0) continue;
+        const double *cj = A + j * m;
+        for (int64_t i = 0; i < m; ++i) Av[i] += cj[i] * vj;
+    }
+    for (int64_t i = 0; i < m; ++i) out[i] = b[i] - Av[i];
+    free(Av);
+}
+
+eo_phase *eo_primal_phase1(const eo_problem *prob, int *err) {
+    if (err) *err = 0;
+    eo_phase *sf = standard_form(prob);
+    if (!sf) return NULL;
+    const int64_t n = sf->n, m = sf->m;
+
+    int64_t *N = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n + m + 1));
+    uint8_t *Nb = (uint8_t *)xmalloc((size_t)(n + m + 1));
+    int64_t *B = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n + m + 1));
+    int64_t nN = 0, nB = 0;
+    double *v = (double *)xcalloc((size_t)(n + m + 1), sizeof(double));
+
+    for (int64_t i = 0; i < n; ++i) {
+        switch (sf->kind[i]) {
+        case EO_FREE: break;
+        case EO_LOWER: v[i] = sf->lb[i]; N[nN] = i; Nb[nN++] = EO_NB_LOWER; break;
+        case EO_UPPER: v[i] = sf->ub[i]; N[nN] = i; Nb[nN++] = EO_NB_UPPER; break;
+        case EO_TWOSIDED: v[i] = sf->lb[i]; N[nN] = i; Nb[nN++] = EO_NB_LOWER; break;
+        case EO_FIXED: v[i] = sf->lb[i]; N[nN] = i; Nb[nN++] = EO_NB_LOWER; break;
+        }
+    }
+
+    int64_t nfree = 0;
+    int64_t *free_vars = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n + 1));
+    for (int64_t i = 0; i < n; ++i)
+        if (sf->kind[i] == EO_FREE) free_vars[nfree++] = i;
+
+    /* kind/lb/ub of the phase (copy; free vars beyond the rank become Fixed(0)) */
+    uint8_t *kind = (uint8_t *)xmalloc((size_t)(n + m + 1));
+    double *lb = (double *)xcalloc((size_t)(n + m + 1), sizeof(double));
+    double *ub = (double *)xcalloc((size_t)(n + m + 1), sizeof(double));
+    memcpy(kind, sf->kind, (size_t)n);
+    memcpy(lb, sf->lb, sizeof(double) * (size_t)n);
+    memcpy(ub, sf->ub, sizeof(double) * (size_t)n);
+
+    eo_phase *ph = NULL;
+    const int A_empty = (m == 0 || n == 0);
+
+    if (nfree > 0 && !A_empty) {
+        double *AF = (double *)xmalloc(sizeof(double) * (size_t)(m * nfree));
+        for (int64_t k = 0; k < nfree; ++k)
+            memcpy(AF + k * m, sf->A + free_vars[k] * m, sizeof(double) * (size_t)m);
+        fplu_t f;
+        fplu_factor(&f, AF, m, nfree);
+        free(AF);
+        const int64_t max_rank = m < nfree ? m : nfree;
+        int64_t rank = nfree; /* unwrap_or_else(|| free_vars.len()) :175 */
+        for (int64_t i = 0; i < max_rank; ++i) {
+            if (fabs(f.lu[i + i * m]) < EPS) {
+                rank = i;
+                break;
+            }
+        }
+        if (rank > max_rank) {
+            /* the reference would panic slicing L/U (rank x rank) :202-205 */
+            if (err) *err = EO_ERR_PANIC;
+            fplu_free(&f);
+            goto fail;
+        }
+        perm_rows_i(&f.q, free_vars);
+        for (int64_t k = 0; k < rank; ++k) B[nB++] = free_vars[k];
+        for (int64_t k = rank; k < nfree; ++k) {
+            int64_t i = free_vars[k];
+            kind[i] = EO_FIXED;
+            lb[i] = 0.0;
+            ub[i] = 0.0;
+            N[nN] = i;
+            Nb[nN++] = EO_NB_LOWER;
+        }
+        double *bt = (double *)xmalloc(sizeof(double) * (size_t)(m + 1));
+        matvec_sub(sf->A, m, n, v, sf->b, bt);
+        perm_rows_d(&f.p, bt);
+        /* L (unit lower) y = bt[0..rank] ; U z = y, both column-oriented, rank x rank slices */
+        for (int64_t i = 0; i < rank; ++i) {
+            double coeff = bt[i] / 1.0;
+            bt[i] = coeff;
+            for (int64_t r = i + 1; r < rank; ++r) bt[r] = (-coeff) * f.lu[r + i * m] + bt[r];
+        }
+        for (int64_t i = rank - 1; i >= 0; --i) {
+            double diag = f.lu[i + i * m];
+            if (diag == 0.0) {
+                if (err) *err = EO_ERR_PANIC; /* unwrap() on None :210 */
+                free(bt);
+                fplu_free(&f);
+                goto fail;
+            }
+            double coeff = bt[i] / diag;
+            bt[i] = coeff;
+            for (int64_t r = 0; r < i; ++r) bt[r] = (-coeff) * f.lu[r + i * m] + bt[r];
+        }
+        for (int64_t k = 0; k < rank; ++k) v[free_vars[k]] = bt[k];
+
+        int64_t *rows = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(m + 1));
+        for (int64_t i = 0; i < m; ++i) rows[i] = i;
+        perm_rows_i(&f.p, rows);
+        const int64_t nart = m - rank;
+
+        matvec_sub(sf->A, m, n, v, sf->b, bt); /* b_tilde with the free basics set :222 */
+
+        ph = phase_alloc(m, n + nart, n + m);
+        memcpy(ph->A, sf->A, sizeof(double) * (size_t)(m * n));
+        int64_t cur_col = n + nart - 1;
+        for (int64_t k = rank; k < m; ++k) {
+            int64_t i = rows[k];
+            v[cur_col] = fabs(bt[i]);
+            ph->A[i + cur_col * m] = rust_signum(bt[i]);
+            B[nB++] = cur_col;
+            cur_col -= 1;
+        }
+        free(rows);
+        free(bt);
+        fplu_free(&f);
+    } else {
+        double *bt = (double *)xmalloc(sizeof(double) * (size_t)(m + 1));
+        matvec_sub(sf->A, m, n, v, sf->b, bt);
+        ph = phase_alloc(m, n + m, n + m);
+        memcpy(ph->A, sf->A, sizeof(double) * (size_t)(m * n));
+        for (int64_t i = 0; i < m; ++i) {
+            int64_t index = n + i;
+            v[index] = fabs(bt[i]);
+            ph->A[i + index * m] = rust_signum(bt[i]);
+            B[nB++] = index;
+        }
+        free(bt);
+    }
+
+    /* c = 0 on the first n, 1 on the m appended :137-141 */
+    for (int64_t i = 0; i < n; ++i) ph->c[i] = 0.0;
+    for (int64_t i = n; i < n + m; ++i) ph->c[i] = 1.0;
+    memcpy(ph->b, sf->b, sizeof(double) * (size_t)m);
+    memcpy(ph->kind, kind, (size_t)n);
+    memcpy(ph->lb, lb, sizeof(double) * (size_t)n);
+    memcpy(ph->ub, ub, sizeof(double) * (size_t)n);
+    ph->n_p1vars = m;
+    ph->p1vars = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(m + 1));
+    for (int64_t i = 0; i < m; ++i) { /* :250-253 */
+        ph->p1vars[i] = n + i;
+        ph->kind[n + i] = EO_LOWER;
+        ph->lb[n + i] = 0.0;
+        ph->ub[n + i] = 0.0;
+    }
+    memcpy(ph->x, v, sizeof(double) * (size_t)(n + m));
+    memcpy(ph->B, B, sizeof(int64_t) * (size_t)nB);
+    memcpy(ph->N, N, sizeof(int64_t) * (size_t)nN);
+    memcpy(ph->Nb, Nb, (size_t)nN);
+    ph->nB = nB;
+    ph->nN = nN;
+    ph->which = 1;
+    phase_copy_orig(ph, sf);
+
+fail:
+    free(N); free(Nb); free(B); free(v); free(free_vars); free(kind); free(lb); free(ub);
+    eo_phase_free(sf);
+    return ph;
+}
+
+static eo_phase *phase_clone_core(const eo_phase *s) {
+    eo_phase *ph = phase_alloc(s->m, s->n, s->n_c);
+    memcpy(ph->A, s->A, sizeof(double) * (size_t)(s->m * s->n));
+    memcpy(ph->c, s->c, sizeof(double) * (size_t)s->n_c);
+    memcpy(ph->b, s->b, sizeof(double) * (size_t)s->m);
+    memcpy(ph->kind, s->kind, (size_t)s->n_c);
+    memcpy(ph->lb, s->lb, sizeof(double) * (size_t)s->n_c);
+    memcpy(ph->ub, s->ub, sizeof(double) * (size_t)s->n_c);
+    memcpy(ph->x, s->x, sizeof(double) * (size_t)s->n_c);
+    memcpy(ph->B, s->B, sizeof(int64_t) * (size_t)s->nB);
+    memcpy(ph->N, s->N, sizeof(int64_t) * (size_t)s->nN);
+    memcpy(ph->Nb, s->Nb, (size_t)s->nN);
+    ph->nB = s->nB;
+    ph->nN = s->nN;
+    phase_copy_orig(ph, s);
+    return ph;
+}
+
+/* primal_problem.rs:263-291 */
+eo_phase *eo_primal_phase2(const eo_phase *p1) {
+    eo_phase *ph = phase_clone_core(p1);
+    for (int64_t k = 0; k < p1->n_p1vars; ++k) {
+        int64_t i = p1->p1vars[k];
+        ph->c[i] = 0.0;
+        ph->kind[i] = EO_FIXED;
+        ph->lb[i] = 0.0;
+        ph->ub[i] = 0.0;
+    }
+    for (int64_t i = 0; i < p1->n_orig_vars; ++i) {
+        ph->c[i] = p1->orig_obj[i];
+        ph->kind[i] = p1->orig_kind[i];
+        ph->lb[i] = p1->orig_lb[i];
+        ph->ub[i] = p1->orig_ub[i];
+    }
+    for (int64_t k = 0; k < ph->nN; ++k)
+        if (ph->kind[ph->N[k]] == EO_FREE) ph->Nb[k] = EO_NB_FREE;
+    ph->which = 2;
+    return ph;
+}
+
+/* ------------------------------------------------------------------ trivial solver
+ * solvers/trivial/solve_trivial_problem.rs:5-96 (quirk Q8 kept) */
+static int solve_trivial(int64_t n_c, const double *c, const uint8_t *kind, const double *lb,
+                         const double *ub, double *x, int64_t *N, uint8_t *Nb, int64_t *nN,
+                         int minimize) {
+    int64_t k = 0;
+    for (int64_t i = 0; i < n_c; ++i) {
+        double ci = c[i];
+        switch (kind[i]) {
+        case EO_FREE:
+            N[k] = i; Nb[k++] = EO_NB_FREE;
+            if (ci != 0.0) { *nN = k; return EO_UNBOUNDED; }
+            x[i] = 0.0;
+            break;
+        case EO_LOWER:
+            N[k] = i; Nb[k++] = EO_NB_LOWER;
+            if (ci > 0.0) {
+                if (minimize) x[i] = lb[i];
+                else { *nN = k; return EO_UNBOUNDED; }
+            } else {
+                if (minimize) x[i] = lb[i];
+                else if (ci != 0.0) { *nN = k; return EO_UNBOUNDED; }
+                else x[i] = lb[i];
+            }
+            break;
+        case EO_UPPER:
+            N[k] = i; Nb[k++] = EO_NB_UPPER;
+            if (ci > 0.0) {
+                if (minimize) { *nN = k; return EO_UNBOUNDED; }
+                else x[i] = ub[i];
+            } else {
+                if (minimize) {
+                    if (ci != 0.0) { *nN = k; return EO_UNBOUNDED; }
+                    else x[i] = ub[i];
+                } else x[i] = ub[i];
+            }
+            break;
+        case EO_TWOSIDED:
+            if ((ci > 0.0) == (minimize != 0)) {
+                N[k] = i; Nb[k++] = EO_NB_LOWER; x[i] = lb[i];
+            } else {
+                N[k] = i; Nb[k++] = EO_NB_UPPER; x[i] = ub[i];
+            }
+            break;
+        case EO_FIXED:
+            N[k] = i; Nb[k++] = EO_NB_LOWER; x[i] = lb[i];
+            break;
+        }
+    }
+    *nN = k;
+    return EO_OPTIMAL;
+}
+
+/* ------------------------------------------------------------------ primal hot loop
+ * primal_simplex_solver.rs:95-436 */
+int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,
+                                 const double *c, const double *b, const uint8_t *kind,
+                                 const double *lb, const double *ub, double *x, int64_t *B,
+                                 int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
+                                 uint64_t max_iter, uint64_t *iters_out, char *err,
+                                 size_t errlen) {
+    (void)b;
+    if (iters_out) *iters_out = 0;
+    if (m == 0) { /* :118-122 */
+        if (nB != 0) {
+            set_err(err, errlen, "assertion failed: B.is_empty()");
+            return EO_ERR_PANIC;
+        }
+        int64_t k = 0;
+        /* the caller's N buffer must hold n_c entries in this case */
+        return solve_trivial(n_c, c, kind, lb, ub, x, N, Nb, &k, 1);
+    }
+    if (nB != m) { /* :124-130 */
+        if (err && errlen)
+            snprintf(err, errlen, "invalid B, has %lld elements but %lld expected", (long long)nB,
+                     (long long)m);
+        return EO_ERR_BAD_DIMS;
+    }
+    if (n < m) {
+        set_err(err, errlen, "checked_sub overflow: cols < rows");
+        return EO_ERR_PANIC;
+    }
+    if (nN != n - m) { /* :132-140 */
+        if (err && errlen)
+            snprintf(err, errlen, "invalid N, has %lld elements but %lld expected", (long long)nN,
+                     (long long)(n - m));
+        return EO_ERR_BAD_DIMS;
+    }
+    if (nN == 0) return EO_OPTIMAL; /* :149-151 */
+
+    double *A_B = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *c_B = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *A_N = (double *)xmalloc(sizeof(double) * (size_t)(m * nN));
+    double *c_N = (double *)xmalloc(sizeof(double) * (size_t)nN);
+    for (int64_t i = 0; i < m; ++i) {
+        memcpy(A_B + i * m, A + B[i] * m, sizeof(double) * (size_t)m);
+        c_B[i] = c[B[i]];
+    }
+    for (int64_t j = 0; j < nN; ++j) {
+        memcpy(A_N + j * m, A + N[j] * m, sizeof(double) * (size_t)m);
+        c_N[j] = c[N[j]];
+    }
+    double *u = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *r = (double *)xmalloc(sizeof(double) * (size_t)nN);
+    double *d = (double *)xmalloc(sizeof(double) * (size_t)m);
+    lu_t f;
+    f.lu = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    f.nr = f.nc = m;
+    perm_init(&f.p, m + 1);
+
+    int status = EO_ERR_PANIC;
+    uint64_t iter = 1;
+    uint64_t entered = 0;
+    for (;;) {
+        if (iter > max_iter) { /* :163-166 */
+            status = EO_MAXITER;
+            break;
+        }
+        iter += 1;
+        entered += 1;
+
+        /* :173  lu = A_B.clone().lu() */
+        memcpy(f.lu, A_B, sizeof(double) * (size_t)(m * m));
+        f.p.len = 0;
+        lu_factor_inplace(&f);
+        if (lu_small_diag(&f)) { /* :175-179 */
+            set_err(err, errlen, "invalid B, A_B is not invertible");
+            status = EO_ERR_SINGULAR;
+            break;
+        }
+        /* :184-187 BTRAN */
+        memcpy(u, c_B, sizeof(double) * (size_t)m);
+        if (!lu_btran(&f, u)) {
+            set_err(err, errlen, "unwrap() on None in BTRAN");
+            status = EO_ERR_PANIC;
+            break;
+        }
+        /* :189 pricing r = c_N - A_N^T u */
+        for (int64_t j = 0; j < nN; ++j) {
+            const double *cj = A_N + j * m;
+            double dot = 0.0;
+            for (int64_t i = 0; i < m; ++i) dot += cj[i] * u[i];
+            r[j] = c_N[j] - dot;
+        }
+
+        /* ---- pivot() :238-435 ---- entering: sequential max_by fold :253-287 */
+        int have = 0;
+        double r1 = 0.0;
+        int64_t q = -1;
+        int nan_seen = 0;
+        for (int64_t j = 0; j < nN; ++j) {
+            double rj = r[j];
+            if (fabs(rj) < EPS) continue;
+            double key;
+            int pos = rj > 0.0;
+            if (pos && Nb[j] == EO_NB_UPPER) key = rj;
+            else if (!pos && Nb[j] == EO_NB_LOWER) key = -rj;
+            else if (Nb[j] == EO_NB_FREE) key = fabs(rj);
+            else continue;
+            if (!have) {
+                have = 1;
+                r1 = key;
+                q = j;
+                continue;
+            }
+            /* max_by keeps acc only if compare(acc, new) == Greater */
+            int acc_greater;
+            if (fabs(r1 - key) >= EPS) {
+                /* partial_cmp(..).expect("NaN detected") can never see a NaN here: a NaN
+                 * operand makes the '>= EPS' test false and falls to the index rule. */
+                acc_greater = r1 > key;
+            } else {
+                acc_greater = N[q] > N[j];
+            }
+            if (!acc_greater) {
+                r1 = key;
+                q = j;
+            }
+        }
+        if (nan_seen) {
+            set_err(err, errlen, "NaN detected");
+            status = EO_ERR_NAN;
+            break;
+        }
+        if (!have) { /* :289-292 */
+            status = EO_OPTIMAL;
+            break;
+        }
+        const int64_t jq = N[q];
+        /* :295-300 FTRAN */
+        memcpy(d, A + jq * m, sizeof(double) * (size_t)m);
+        if (!lu_solve(&f, d)) {
+            set_err(err, errlen, "unwrap() on None in FTRAN");
+            status = EO_ERR_PANIC;
+            break;
+        }
+        const int at_lower = (Nb[q] == EO_NB_LOWER);
+        if (at_lower)
+            for (int64_t i = 0; i < m; ++i) d[i] = -d[i];
+
+        double lambda; /* :305-311 */
+        switch (kind[jq]) {
+        case EO_TWOSIDED: lambda = ub[jq] - lb[jq]; break;
+        case EO_FIXED: lambda = 0.0; break;
+        default: lambda = INFINITY; break;
+        }
+        int64_t new_basic = -1;
+        int new_side = EO_NB_LOWER;
+        int have_nbi = 0;
+        int64_t nbi = 0;
+        for (int64_t i = 0; i < m; ++i) { /* :320-400 */
+            double di = d[i];
+            if (fabs(di) < EPS) continue;
+            const int64_t bi = B[i];
+            double xi = x[bi];
+            double li;
+            switch (kind[bi]) {
+            case EO_FREE: li = INFINITY; break;
+            case EO_LOWER:
+                if (di > 0.0) li = INFINITY;
+                else if (xi > lb[bi]) li = (lb[bi] - xi) / di;
+                else li = 0.0;
+                break;
+            case EO_UPPER:
+                if (di > 0.0) li = (xi < ub[bi]) ? (ub[bi] - xi) / di : 0.0;
+                else li = INFINITY;
+                break;
+            case EO_TWOSIDED:
+                if (di > 0.0) li = (xi < ub[bi]) ? (ub[bi] - xi) / di : 0.0;
+                else if (xi < lb[bi]) li = (lb[bi] - xi) / di; /* quirk Q1 :359 */
+                else li = 0.0;
+                break;
+            default: li = 0.0; break; /* Fixed */
+            }
+            if (li < lambda - EPS) {
+                lambda = li;
+                new_basic = i;
+                new_side = (di > 0.0) ? EO_NB_UPPER : EO_NB_LOWER;
+            } else if (fabs(li - lambda) < EPS) {
+                if (!have_nbi || bi < nbi) {
+                    have_nbi = 1;
+                    nbi = bi;
+                    lambda = li;
+                    new_basic = i;
+                    new_side = (di > 0.0) ? EO_NB_UPPER : EO_NB_LOWER;
+                }
+            }
+        }
+        if (!(lambda >= 0.0)) { /* :402 */
+            set_err(err, errlen, "assertion failed: lambda >= 0.");
+            status = EO_ERR_PANIC;
+            break;
+        }
+        if (isinf(lambda)) { /* :404-406 */
+            status = EO_UNBOUNDED;
+            break;
+        }
+        if (lambda > 0.0) { /* :408-417 */
+            for (int64_t i = 0; i < m; ++i) x[B[i]] += lambda * d[i];
+            if (at_lower) x[jq] += lambda;
+            else x[jq] -= lambda;
+        }
+        if (g_trace)
+            g_trace(g_trace_user, entered, q, new_basic, jq, new_basic >= 0 ? B[new_basic] : -1);
+        /* :205-232 apply the pivot */
+        if (new_basic >= 0) {
+            int64_t t = B[new_basic];
+            B[new_basic] = N[q];
+            N[q] = t;
+            double *cn = A_N + q * m, *cb = A_B + new_basic * m;
+            for (int64_t i = 0; i < m; ++i) {
+                double tt = cn[i];
+                cn[i] = cb[i];
+                cb[i] = tt;
+            }
+            double tc = c_N[q];
+            c_N[q] = c_B[new_basic];
+            c_B[new_basic] = tc;
+            Nb[q] = (uint8_t)new_side;
+        } else {
+            if (Nb[q] == EO_NB_LOWER) Nb[q] = EO_NB_UPPER;
+            else if (Nb[q] == EO_NB_UPPER) Nb[q] = EO_NB_LOWER;
+            else {
+                set_err(err, errlen, "pivot should have been unbounded");
+                status = EO_ERR_PANIC;
+                break;
+            }
+        }
+    }
+    if (iters_out) *iters_out = entered;
+    lu_free(&f);
+    free(A_B); free(c_B); free(A_N); free(c_N); free(u); free(r); free(d);
+    return status;
+}
+
+/* ------------------------------------------------------------------ dual hot loop
+ * dual_simplex_solver.rs:110-335 */
+int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,
+                               const double *c, const double *b, const uint8_t *kind,
+                               const double *lb, const double *ub, double *x, int64_t *B,
+                               int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y,
+                               double *d, uint64_t max_iter, uint64_t *iters_out, char *err,
+                               size_t errlen) {
+    if (iters_out) *iters_out = 0;
+    if (m == 0) { /* :132-136 */
+        if (nB != 0) {
+            set_err(err, errlen, "assertion failed: B.is_empty()");
+            return EO_ERR_PANIC;
+        }
+        int64_t k = 0;
+        return solve_trivial(n_c, c, kind, lb, ub, x, N, Nb, &k, 1);
+    }
+    for (int64_t j = 0; j < nN; ++j) { /* :139-151 */
+        double di = d[N[j]];
+        int infeasible;
+        if (Nb[j] == EO_NB_LOWER) infeasible = di < -EPS;
+        else if (Nb[j] == EO_NB_UPPER) infeasible = di > EPS;
+        else infeasible = fabs(di) > EPS;
+        if (infeasible) {
+            set_err(err, errlen, "initial point of dual phase 2 is dual infeasible");
+            return EO_ERR_PANIC;
+        }
+    }
+    if (nB != m) {
+        if (err && errlen)
+            snprintf(err, errlen, "invalid B, has %lld elements but %lld expected", (long long)nB,
+                     (long long)m);
+        return EO_ERR_BAD_DIMS;
+    }
+    if (n < m) {
+        set_err(err, errlen, "checked_sub overflow: cols < rows");
+        return EO_ERR_PANIC;
+    }
+    if (nN != n - m) {
+        if (err && errlen)
+            snprintf(err, errlen, "invalid N, has %lld elements but %lld expected", (long long)nN,
+                     (long long)(n - m));
+        return EO_ERR_BAD_DIMS;
+    }
+    if (nN == 0) return EO_OPTIMAL; /* :175-177 */
+
+    double *A_B = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *A_N = (double *)xmalloc(sizeof(double) * (size_t)(m * nN));
+    for (int64_t i = 0; i < m; ++i)
+        memcpy(A_B + i * m, A + B[i] * m, sizeof(double) * (size_t)m);
+    for (int64_t j = 0; j < nN; ++j)
+        memcpy(A_N + j * m, A + N[j] * m, sizeof(double) * (size_t)m);
+    double *rho = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *alpha = (double *)xmalloc(sizeof(double) * (size_t)nN);
+    double *alpha_q = (double *)xmalloc(sizeof(double) * (size_t)m);
+    lu_t f;
+    f.lu = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    f.nr = f.nc = m;
+    perm_init(&f.p, m + 1);
+
+    int status = EO_ERR_PANIC;
+    uint64_t iter = 0, entered = 0;
+    double obj = dual_obj(m, n_c, b, kind, lb, ub, y, d); /* :184 */
+    (void)obj;
+    for (;;) {
+        if (iter >= max_iter) { /* :191-194 */
+            status = EO_MAXITER;
+            break;
+        }
+        iter += 1;
+        entered += 1;
+        /* leaving: first violated basic in B order :200-236 */
+        int64_t r = -1;
+        double delta = 0.0;
+        int side = EO_NB_LOWER;
+        for (int64_t i = 0; i < m && r < 0; ++i) {
+            const int64_t bi = B[i];
+            double xi = x[bi];
+            switch (kind[bi]) {
+            case EO_LOWER:
+                if (xi < lb[bi] - EPS) { r = i; delta = xi - lb[bi]; side = EO_NB_LOWER; }
+                break;
+            case EO_UPPER:
+                if (xi > ub[bi] + EPS) { r = i; delta = xi - ub[bi]; side = EO_NB_UPPER; }
+                break;
+            case EO_TWOSIDED:
+                if (xi > ub[bi] + EPS) { r = i; delta = xi - ub[bi]; side = EO_NB_UPPER; }
+                else if (xi < lb[bi] - EPS) { r = i; delta = xi - lb[bi]; side = EO_NB_LOWER; }
+                break;
+            default: break; /* Free, Fixed never leave (quirk Q3) */
+            }
+        }
+        /* :241 LU before the optimality test (quirk Q4) */
+        memcpy(f.lu, A_B, sizeof(double) * (size_t)(m * m));
+        f.p.len = 0;
+        lu_factor_inplace(&f);
+        if (r < 0) { /* :243-246 */
+            status = EO_OPTIMAL;
+            break;
+        }
+        /* :248-253 rho = row r of A_B^{-1} */
+        memset(rho, 0, sizeof(double) * (size_t)m);
+        rho[r] = 1.0;
+        if (!lu_btran(&f, rho)) {
+            set_err(err, errlen, "unwrap() on None in dual BTRAN");
+            status = EO_ERR_PANIC;
+            break;
+        }
+        /* :255-259 alpha = A_N^T rho, negated if delta < 0 */
+        for (int64_t j = 0; j < nN; ++j) {
+            const double *cj = A_N + j * m;
+            double dot = 0.0;
+            for (int64_t i = 0; i < m; ++i) dot += cj[i] * rho[i];
+            alpha[j] = (delta < 0.0) ? -dot : dot;
+        }
+        /* :263-279 entering: first minimum of d/alpha over eligible */
+        int64_t q = -1;
+        double theta_dual = 0.0;
+        int nan_seen = 0;
+        for (int64_t j = 0; j < nN; ++j) {
+            int keep;
+            if (Nb[j] == EO_NB_LOWER) keep = alpha[j] > EPS;
+            else if (Nb[j] == EO_NB_UPPER) keep = alpha[j] < -EPS;
+            else keep = 1;
+            if (!keep) continue;
+            double ratio = d[N[j]] / alpha[j];
+            if (q < 0) {
+                q = j;
+                theta_dual = ratio;
+            } else {
+                if (isnan(ratio) || isnan(theta_dual)) {
+                    nan_seen = 1;
+                    break;
+                }
+                /* min_by keeps acc unless compare(acc,new) == Greater */
+                if (theta_dual > ratio) {
+                    q = j;
+                    theta_dual = ratio;
+                }
+            }
+        }
+        if (nan_seen) {
+            set_err(err, errlen, "unwrap() on None: NaN in dual ratio test");
+            status = EO_ERR_NAN;
+            break;
+        }
+        if (q < 0) { /* :281-284 dual unbounded */
+            status = EO_INFEASIBLE;
+            break;
+        }
+        if (delta < 0.0) { /* :286-289 */
+            for (int64_t j = 0; j < nN; ++j) alpha[j] = -alpha[j];
+            theta_dual = -theta_dual;
+        }
+        const int64_t leaving_var = B[r];
+        const int64_t entering_var = N[q];
+        memcpy(alpha_q, A + entering_var * m, sizeof(double) * (size_t)m);
+        if (!lu_solve(&f, alpha_q)) { /* :294 */
+            set_err(err, errlen, "unwrap() on None in dual FTRAN");
+            status = EO_ERR_PANIC;
+            break;
+        }
+        d[leaving_var] = -theta_dual; /* :296-304 */
+        for (int64_t j = 0; j < nN; ++j) d[N[j]] -= theta_dual * alpha[j];
+        d[entering_var] = 0.0;
+        for (int64_t i = 0; i < m; ++i) y[i] += theta_dual * rho[i];
+        double theta_primal = delta / alpha_q[r]; /* :306-316 */
+        for (int64_t i = 0; i < m; ++i) x[B[i]] -= theta_primal * alpha_q[i];
+        x[entering_var] += theta_primal;
+        obj += theta_dual * delta;
+        if (g_trace) g_trace(g_trace_user, entered, q, r, entering_var, leaving_var);
+        /* :322-333 */
+        B[r] = entering_var;
+        N[q] = leaving_var;
+        Nb[q] = (uint8_t)side;
+        double *cb = A_B + r * m, *cn = A_N + q * m;
+        for (int64_t i = 0; i < m; ++i) {
+            double t = cb[i];
+            cb[i] = cn[i];
+            cn[i] = t;
+        }
+    }
+    if (iters_out) *iters_out = entered;
+    lu_free(&f);
+    free(A_B); free(A_N); free(rho); free(alpha); free(alpha_q);
+    return status;
+}
+
+/* ------------------------------------------------------------------ DualPhase1 / DualPhase2 */
+
+static eo_problem *problem_clone(const eo_problem *p) {
+    eo_problem *q = eo_problem_new();
+    for (int64_t i = 0; i < p->nvars; ++i)
+        eo_add_var_with_id(q, p->vars[i].obj, p->vars[i].kind, p->vars[i].lb, p->vars[i].ub,
+                           p->vars[i].id);
+    for (int64_t i = 0; i < p->ncons; ++i)
+        eo_add_constraint(q, p->cons[i].n, p->cons[i].ids, p->cons[i].coef, p->cons[i].op,
+                          p->cons[i].rhs);
+    return q;
+}
+
+/* y = A_B^{-T} c_B, d = c - A^T y  (dual_problem.rs:162-172, 276-283) */
+static int dual_y_d(const eo_phase *sf, const int64_t *B, lu_t *f, double *y, double *d) {
+    const int64_t m = sf->m, n = sf->n;
+    double *A_B = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    for (int64_t i = 0; i < m; ++i) {
+        memcpy(A_B + i * m, sf->A + B[i] * m, sizeof(double) * (size_t)m);
+        y[i] = sf->c[B[i]];
+    }
+    lu_factor(f, A_B, m, m);
+    free(A_B);
+    if (!lu_btran(f, y)) return 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const double *cj = sf->A + j * m;
+        double dot = 0.0;
+        for (int64_t i = 0; i < m; ++i) dot += cj[i] * y[i];
+        d[j] = sf->c[j] - dot;
+    }
+    return 1;
+}
+
+/* dual_problem.rs:89-256 */
+eo_phase *eo_dual_phase1(const eo_problem *prob, int *err) {
+    if (err) *err = 0;
+    eo_phase *orig = standard_form(prob);
+    if (!orig) return NULL;
+    const int64_t on = orig->n, om = orig->m;
+
+    eo_problem *p1 = eo_problem_new();
+    uint8_t *kept = (uint8_t *)xcalloc((size_t)(on + 1), 1);
+    for (int64_t i = 0; i < on; ++i) { /* :99-112 */
+        switch (orig->kind[i]) {
+        case EO_FREE: kept[i] = 1; eo_add_var_with_id(p1, orig->c[i], EO_TWOSIDED, -1.0, 1.0, i); break;
+        case EO_LOWER: kept[i] = 1; eo_add_var_with_id(p1, orig->c[i], EO_TWOSIDED, 0.0, 1.0, i); break;
+        case EO_UPPER: kept[i] = 1; eo_add_var_with_id(p1, orig->c[i], EO_TWOSIDED, -1.0, 0.0, i); break;
+        default: break;
+        }
+    }
+    {
+        int64_t *ids = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(on + 1));
+        double *cf = (double *)xmalloc(sizeof(double) * (size_t)(on + 1));
+        for (int64_t i = 0; i < om; ++i) { /* :114-134 */
+            int64_t k = 0;
+            for (int64_t j = 0; j < on; ++j) {
+                if (kept[j]) {
+                    ids[k] = j;
+                    cf[k] = orig->A[i + j * om];
+                    k++;
+                }
+            }
+            if (k > 0) eo_add_constraint(p1, k, ids, cf, EO_EQ, 0.0);
+        }
+        free(ids);
+        free(cf);
+    }
+    free(kept);
+
+    eo_phase *sf = standard_form(p1); /* :136 */
+    if (!sf) {
+        eo_problem_free(p1);
+        eo_phase_free(orig);
+        return NULL;
+    }
+    const int64_t n = sf->n, m = sf->m;
+    /* remember the id of each box-problem variable (phase_1_prob.variables[k].id) */
+    sf->p1ids = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n + 1));
+    for (int64_t k = 0; k < p1->nvars; ++k) sf->p1ids[k] = p1->vars[k].id;
+    eo_problem_free(p1);
+
+    /* :141-160 basis from LU(A^T) */
+    double *At = (double *)xmalloc(sizeof(double) * (size_t)(n * m + 1));
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) At[j + i * n] = sf->A[i + j * m];
+    lu_t ft;
+    lu_factor(&ft, At, n, m);
+    free(At);
+    if (lu_small_diag(&ft) || n < m) {
+        if (err) *err = EO_ERR_PANIC; /* "should always have a basis available" */
+        lu_free(&ft);
+        eo_phase_free(sf);
+        eo_phase_free(orig);
+        return NULL;
+    }
+    int64_t *perm_cols = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(n + 1));
+    for (int64_t j = 0; j < n; ++j) perm_cols[j] = j;
+    perm_rows_i(&ft.p, perm_cols);
+    lu_free(&ft);
+    for (int64_t i = 0; i < m; ++i) sf->B[i] = perm_cols[i];
+    sf->nB = m;
+    for (int64_t k = m; k < n; ++k) {
+        sf->N[k - m] = perm_cols[k];
+        sf->Nb[k - m] = EO_NB_LOWER;
+    }
+    sf->nN = n - m;
+    free(perm_cols);
+
+    sf->y = (double *)xcalloc((size_t)(m + 1), sizeof(double));
+    sf->d = (double *)xcalloc((size_t)(n + 1), sizeof(double));
+    if (m > 0) { /* :166-226 */
+        lu_t f;
+        if (!dual_y_d(sf, sf->B, &f, sf->y, sf->d)) {
+            if (err) *err = EO_ERR_PANIC;
+            lu_free(&f);
+            eo_phase_free(sf);
+            eo_phase_free(orig);
+            return NULL;
+        }
+        for (int64_t k = 0; k < sf->nN; ++k) {
+            int64_t i = sf->N[k];
+            if (sf->kind[i] == EO_TWOSIDED) {
+                if (sf->d[i] >= 0.0) { sf->x[i] = sf->lb[i]; sf->Nb[k] = EO_NB_LOWER; }
+                else { sf->x[i] = sf->ub[i]; sf->Nb[k] = EO_NB_UPPER; }
+            } else if (sf->kind[i] == EO_FIXED) {
+                sf->x[i] = sf->lb[i];
+                sf->Nb[k] = (sf->d[i] >= 0.0) ? EO_NB_LOWER : EO_NB_UPPER;
+            } else {
+                if (err) *err = EO_ERR_PANIC;
+                lu_free(&f);
+                eo_phase_free(sf);
+                eo_phase_free(orig);
+                return NULL;
+            }
+        }
+        double *bt = (double *)xmalloc(sizeof(double) * (size_t)(m + 1));
+        matvec_sub(sf->A, m, n, sf->x, sf->b, bt);
+        if (!lu_solve(&f, bt)) {
+            if (err) *err = EO_ERR_PANIC;
+            free(bt);
+            lu_free(&f);
+            eo_phase_free(sf);
+            eo_phase_free(orig);
+            return NULL;
+        }
+        for (int64_t i = 0; i < m; ++i) sf->x[sf->B[i]] = bt[i];
+        free(bt);
+        lu_free(&f);
+    } else { /* :227-254 */
+        for (int64_t k = 0; k < sf->nN; ++k) {
+            int64_t i = sf->N[k];
+            sf->Nb[k] = EO_NB_LOWER;
+            if (sf->kind[i] == EO_TWOSIDED || sf->kind[i] == EO_FIXED) sf->x[i] = sf->lb[i];
+            else {
+                if (err) *err = EO_ERR_PANIC;
+                eo_phase_free(sf);
+                eo_phase_free(orig);
+                return NULL;
+            }
+        }
+        memcpy(sf->d, sf->c, sizeof(double) * (size_t)n);
+    }
+    sf->which = 3;
+    sf->orig = orig;
+    /* keep the user's problem data on the phase itself too (for phase 2 / fallback) */
+    free(sf->orig_obj); free(sf->orig_kind); free(sf->orig_lb); free(sf->orig_ub);
+    sf->orig_obj = NULL; sf->orig_kind = NULL; sf->orig_lb = sf->orig_ub = NULL;
+    phase_copy_orig(sf, orig);
+    return sf;
+}
+
+/* dual_problem.rs:258-404 */
+eo_phase *eo_dual_phase2(const eo_phase *p1, int *err) {
+    if (err) *err = 0;
+    const eo_phase *o = p1->orig;
+    const int64_t n = o->n, m = o->m;
+    eo_phase *ph = phase_alloc(m, n, n);
+    memcpy(ph->A, o->A, sizeof(double) * (size_t)(m * n));
+    memcpy(ph->c, o->c, sizeof(double) * (size_t)n);
+    memcpy(ph->b, o->b, sizeof(double) * (size_t)m);
+    memcpy(ph->kind, o->kind, (size_t)n);
+    memcpy(ph->lb, o->lb, sizeof(double) * (size_t)n);
+    memcpy(ph->ub, o->ub, sizeof(double) * (size_t)n);
+    phase_copy_orig(ph, o);
+    ph->which = 4;
+
+    uint8_t *is_basic = (uint8_t *)xcalloc((size_t)(n + 1), 1);
+    for (int64_t i = 0; i < p1->nB; ++i) {
+        int64_t index = p1->p1ids[p1->B[i]];
+        is_basic[index] = 1;
+        ph->B[i] = index;
+    }
+    ph->nB = p1->nB;
+    ph->y = (double *)xcalloc((size_t)(m + 1), sizeof(double));
+    ph->d = (double *)xcalloc((size_t)(n + 1), sizeof(double));
+
+    if (ph->nB > 0) {
+        if (ph->nB != m) { /* select_columns + lu().solve would panic on shape */
+            if (err) *err = EO_ERR_PANIC;
+            free(is_basic);
+            eo_phase_free(ph);
+            return NULL;
+        }
+        lu_t f;
+        if (!dual_y_d(ph, ph->B, &f, ph->y, ph->d)) {
+            if (err) *err = EO_ERR_PANIC;
+            lu_free(&f);
+            free(is_basic);
+            eo_phase_free(ph);
+            return NULL;
+        }
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (is_basic[i]) continue;
+            double di = ph->d[i];
+            double xi = 0.0;
+            int bound = EO_NB_LOWER;
+            switch (ph->kind[i]) {
+            case EO_FREE:
+                if (!(fabs(di) < EPS)) { if (err) *err = EO_ERR_PANIC; }
+                xi = 0.0; bound = EO_NB_FREE; break;
+            case EO_LOWER:
+                if (!(di > -EPS)) { if (err) *err = EO_ERR_PANIC; }
+                xi = ph->lb[i]; bound = EO_NB_LOWER; break;
+            case EO_UPPER:
+                if (!(di < EPS)) { if (err) *err = EO_ERR_PANIC; }
+                xi = ph->ub[i]; bound = EO_NB_UPPER; break;
+            case EO_TWOSIDED:
+                if (di >= 0.0) { xi = ph->lb[i]; bound = EO_NB_LOWER; }
+                else { xi = ph->ub[i]; bound = EO_NB_UPPER; }
+                break;
+            default: xi = ph->lb[i]; bound = EO_NB_LOWER; break;
+            }
+            ph->N[k] = i;
+            ph->Nb[k] = (uint8_t)bound;
+            ph->x[i] = xi;
+            k++;
+        }
+        ph->nN = k;
+        if (err && *err) {
+            lu_free(&f);
+            free(is_basic);
+            eo_phase_free(ph);
+            return NULL;
+        }
+        /* x_B = A_B^{-1} (b - A_N x_N) :326-336 */
+        double *xn = (double *)xcalloc((size_t)(n + 1), sizeof(double));
+        for (int64_t kk = 0; kk < ph->nN; ++kk) xn[ph->N[kk]] = ph->x[ph->N[kk]];
+        double *bt = (double *)xmalloc(sizeof(double) * (size_t)(m + 1));
+        matvec_sub(ph->A, m, n, xn, ph->b, bt);
+        free(xn);
+        if (!lu_solve(&f, bt)) {
+            if (err) *err = EO_ERR_PANIC;
+            free(bt);
+            lu_free(&f);
+            free(is_basic);
+            eo_phase_free(ph);
+            return NULL;
+        }
+        for (int64_t i = 0; i < m; ++i) ph->x[ph->B[i]] = bt[i];
+        free(bt);
+        lu_free(&f);
+    } else { /* :351-402 */
+        int64_t k = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            if (is_basic[i]) continue;
+            int bound;
+            switch (ph->kind[i]) {
+            case EO_FREE: ph->x[i] = 0.0; bound = EO_NB_FREE; break;
+            case EO_LOWER: ph->x[i] = ph->lb[i]; bound = EO_NB_LOWER; break;
+            case EO_UPPER: ph->x[i] = ph->ub[i]; bound = EO_NB_UPPER; break;
+            case EO_TWOSIDED: ph->x[i] = ph->lb[i]; bound = EO_NB_LOWER; break;
+            default: ph->x[i] = ph->lb[i]; bound = EO_NB_LOWER; break;
+            }
+            ph->N[k] = i;
+            ph->Nb[k] = (uint8_t)bound;
+            k++;
+        }
+        ph->nN = k;
+        memcpy(ph->d, ph->c, sizeof(double) * (size_t)n);
+    }
+    free(is_basic);
+    return ph;
+}
+
+/* ------------------------------------------------------------------ solve() drivers */
+
+void eo_result_free(eo_result *r) {
+    if (r && r->x) {
+        free(r->x);
+        r->x = NULL;
+    }
+}
+
+static int run_primal(eo_phase *ph, uint64_t max_iter, uint64_t *iters, char *err, size_t errlen) {
+    int64_t nN = ph->nN;
+    int st = eo_primal_solve_with_initial(ph->m, ph->n, ph->n_c, ph->A, ph->c, ph->b, ph->kind,
+                                          ph->lb, ph->ub, ph->x, ph->B, ph->nB, ph->N, ph->Nb, nN,
+                                          max_iter, iters, err, errlen);
+    if (ph->m == 0) {
+        /* the trivial solver rebuilt N: count what it wrote (every visited variable) */
+        int64_t k = 0;
+        solve_trivial(ph->n_c, ph->c, ph->kind, ph->lb, ph->ub, ph->x, ph->N, ph->Nb, &k, 1);
+        ph->nN = k;
+    }
+    return st;
+}
+static int run_dual(eo_phase *ph, uint64_t max_iter, uint64_t *iters, char *err, size_t errlen) {
+    int st = eo_dual_solve_with_initial(ph->m, ph->n, ph->n_c, ph->A, ph->c, ph->b, ph->kind,
+                                        ph->lb, ph->ub, ph->x, ph->B, ph->nB, ph->N, ph->Nb,
+                                        ph->nN, ph->y, ph->d, max_iter, iters, err, errlen);
+    if (ph->m == 0) {
+        int64_t k = 0;
+        solve_trivial(ph->n_c, ph->c, ph->kind, ph->lb, ph->ub, ph->x, ph->N, ph->Nb, &k, 1);
+        ph->nN = k;
+    }
+    return st;
+}
+
+static void fill_optimal(eo_result *out, const eo_phase *ph) {
+    out->status = EO_OPTIMAL;
+    out->obj = eo_phase_obj(ph); /* solver.rs:46-48 */
+    out->nx = ph->n_orig_vars;   /* standard_form.rs:71-74 */
+    out->x = dcopy(ph->x, ph->n_orig_vars);
+}
+
+/* primal_simplex_solver.rs:32-93 */
+static int solve_primal(const eo_problem *p, uint64_t max_iter, eo_result *out) {
+    int perr = 0;
+    eo_phase *p1 = eo_primal_phase1(p, &perr);
+    if (!p1) {
+        out->status = perr ? perr : EO_INFEASIBLE;
+        return out->status;
+    }
+    int st = run_primal(p1, max_iter, &out->iters1, out->err, sizeof(out->err));
+    if (st < 0) { out->status = st; eo_phase_free(p1); return st; }
+    if (st == EO_OPTIMAL) {
+        double obj = eo_phase_obj(p1);
+        if (!(obj > -EPS)) { /* :43 */
+            out->status = EO_ERR_PANIC;
+            snprintf(out->err, sizeof(out->err), "assertion failed: obj > -EPS");
+            eo_phase_free(p1);
+            return out->status;
+        }
+        if (!(obj < EPS)) { out->status = EO_INFEASIBLE; eo_phase_free(p1); return out->status; }
+    } else if (st == EO_INFEASIBLE) {
+        out->status = EO_INFEASIBLE; eo_phase_free(p1); return out->status;
+    } else if (st == EO_UNBOUNDED) {
+        out->status = EO_ERR_PANIC;
+        snprintf(out->err, sizeof(out->err), "primal phase 1 should never be unbounded");
+        eo_phase_free(p1);
+        return out->status;
+    } else { /* MaxIter :61-64 */
+        out->status = EO_MAXITER; out->obj = INFINITY; eo_phase_free(p1); return out->status;
+    }
+    eo_phase *p2 = eo_primal_phase2(p1);
+    eo_phase_free(p1);
+    st = run_primal(p2, max_iter, &out->iters2, out->err, sizeof(out->err));
+    if (st == EO_OPTIMAL) fill_optimal(out, p2);
+    else if (st == EO_INFEASIBLE) {
+        out->status = EO_ERR_PANIC;
+        snprintf(out->err, sizeof(out->err), "primal phase 2 should never be infeasible");
+    } else if (st == EO_MAXITER) { out->status = EO_MAXITER; out->obj = eo_phase_obj(p2); }
+    else out->status = st;
+    eo_phase_free(p2);
+    return out->status;
+}
+
+/* rebuild the user's Problem from what a phase kept (only for the dual->primal fallback) */
+/* dual_simplex_solver.rs:33-108 */
+static int solve_dual(const eo_problem *p, uint64_t max_iter, eo_result *out) {
+    int perr = 0;
+    eo_phase *p1 = eo_dual_phase1(p, &perr);
+    if (!p1) {
+        out->status = perr ? perr : EO_INFEASIBLE;
+        return out->status;
+    }
+    int st = run_dual(p1, max_iter, &out->iters1, out->err, sizeof(out->err));
+    if (st < 0) { out->status = st; eo_phase_free(p1); return st; }
+    if (st == EO_OPTIMAL) {
+        double obj = eo_phase_dual_obj(p1);
+        if (!(obj < EPS)) { /* :45 */
+            out->status = EO_ERR_PANIC;
+            snprintf(out->err, sizeof(out->err), "assertion failed: obj < EPS");
+            eo_phase_free(p1);
+            return out->status;
+        }
+        if (!(obj > -EPS)) {
+            /* :51-66 classify with PrimalSimplexSolver::default() (max_iter 1000) */
+            eo_phase_free(p1);
+            eo_result r2;
+            memset(&r2, 0, sizeof(r2));
+            eo_problem *pc = problem_clone(p);
+            solve_primal(pc, 1000, &r2);
+            eo_problem_free(pc);
+            if (r2.status == EO_OPTIMAL) {
+                eo_result_free(&r2);
+                out->status = EO_ERR_PANIC;
+                snprintf(out->err, sizeof(out->err),
+                         "dual infeasible but primal fallback found an optimum");
+                return out->status;
+            }
+            out->status = r2.status;
+            out->obj = r2.obj;
+            memcpy(out->err, r2.err, sizeof(out->err));
+            return out->status;
+        }
+    } else if (st == EO_INFEASIBLE || st == EO_UNBOUNDED) {
+        out->status = EO_ERR_PANIC;
+        snprintf(out->err, sizeof(out->err), "dual phase 1 should never be infeasible/unbounded");
+        eo_phase_free(p1);
+        return out->status;
+    } else {
+        out->status = EO_MAXITER; out->obj = INFINITY; eo_phase_free(p1); return out->status;
+    }
+    eo_phase *p2 = eo_dual_phase2(p1, &perr);
+    eo_phase_free(p1);
+    if (!p2) { out->status = perr ? perr : EO_ERR_PANIC; return out->status; }
+    st = run_dual(p2, max_iter, &out->iters2, out->err, sizeof(out->err));
+    if (st == EO_OPTIMAL) fill_optimal(out, p2);
+    else if (st == EO_UNBOUNDED) {
+        out->status = EO_ERR_PANIC;
+        snprintf(out->err, sizeof(out->err), "dual phase 2 should never return unbounded");
+    } else if (st == EO_MAXITER) { out->status = EO_MAXITER; out->obj = eo_phase_dual_obj(p2); }
+    else out->status = st;
+    eo_phase_free(p2);
+    return out->status;
+}
+
+int eo_solve(const eo_problem *p, int solver, uint64_t max_iter, eo_result *out) {
+    memset(out, 0, sizeof(*out));
+    return solver == 0 ? solve_primal(p, max_iter, out) : solve_dual(p, max_iter, out);
+}
+
+/* ------------------------------------------------------------------ synthetic family */
+static inline double sm64_next(uint64_t *s) {
+    *s += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = *s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+void eo_synth_dense_lp(uint64_t seed, int64_t m, int64_t n, double *A, double *b, double *c) {
+    uint64_t s = seed;
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) A[i + j * m] = 0.1 + sm64_next(&s);
+    double *x0 = (double *)xmalloc(sizeof(double) * (size_t)n);
+    for (int64_t j = 0; j < n; ++j) x0[j] = sm64_next(&s);
+    for (int64_t i = 0; i < m; ++i) {
+        double acc = 0.0;
+        for (int64_t j = 0; j < n; ++j) acc += A[i + j * m] * x0[j];
+        b[i] = acc;
+    }
+    for (int64_t j = 0; j < n; ++j) c[j] = -(0.1 + sm64_next(&s));
+    free(x0);
+}

@@ -1,0 +1,321 @@
+"""ctypes binding of the CPU oracle (oracle/ellp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under ellp_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libellp_oracle.so")
+
+KIND = {"Free": 0, "Lower": 1, "Upper": 2, "TwoSided": 3, "Fixed": 4}
+OP = {"Lte": 0, "Eq": 1, "Gte": 2}
+NB_LOWER, NB_UPPER, NB_FREE = 0, 1, 2
+OPTIMAL, INFEASIBLE, UNBOUNDED, MAXITER = 0, 1, 2, 3
+ERR_BAD_DIMS, ERR_SINGULAR, ERR_NAN, ERR_ARG, ERR_PANIC = -1, -2, -3, -5, -6
+MAX_ITER_NONE = 2**64 - 1
+STATUS_NAME = {0: "optimal", 1: "infeasible", 2: "unbounded", 3: "maxiter"}
+
+
+def build(force=False):
+    """Compile libellp_oracle.so with gcc (seconds)."""
+    src = os.path.join(_HERE, "ellp_oracle.c")
+    hdr = os.path.join(_HERE, "ellp_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libellp_oracle.so"])
+    return _LIB_PATH
+
+
+class _Phase(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64), ("n", C.c_int64), ("n_c", C.c_int64),
+        ("A", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double)), ("b", C.POINTER(C.c_double)),
+        ("kind", C.POINTER(C.c_uint8)),
+        ("lb", C.POINTER(C.c_double)), ("ub", C.POINTER(C.c_double)),
+        ("x", C.POINTER(C.c_double)),
+        ("nB", C.c_int64), ("nN", C.c_int64),
+        ("B", C.POINTER(C.c_int64)), ("N", C.POINTER(C.c_int64)),
+        ("Nb", C.POINTER(C.c_uint8)),
+        ("y", C.POINTER(C.c_double)), ("d", C.POINTER(C.c_double)),
+        ("which", C.c_int),
+        ("n_orig_vars", C.c_int64),
+    ]
+
+
+class _Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int), ("obj", C.c_double), ("nx", C.c_int64),
+        ("x", C.POINTER(C.c_double)), ("iters1", C.c_uint64), ("iters2", C.c_uint64),
+        ("err", C.c_char * 256),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    L.eo_problem_new.restype = C.c_void_p
+    L.eo_problem_free.argtypes = [C.c_void_p]
+    L.eo_add_var.restype = C.c_int64
+    L.eo_add_var.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double]
+    L.eo_add_var_with_id.restype = C.c_int64
+    L.eo_add_var_with_id.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double,
+                                     C.c_int64]
+    L.eo_add_constraint.restype = C.c_int
+    L.eo_add_constraint.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_double]
+    L.eo_num_vars.restype = C.c_int64
+    L.eo_num_vars.argtypes = [C.c_void_p]
+    for name in ("eo_primal_phase1", "eo_dual_phase1"):
+        f = getattr(L, name)
+        f.restype = C.POINTER(_Phase)
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.eo_primal_phase2.restype = C.POINTER(_Phase)
+    L.eo_primal_phase2.argtypes = [C.POINTER(_Phase)]
+    L.eo_dual_phase2.restype = C.POINTER(_Phase)
+    L.eo_dual_phase2.argtypes = [C.POINTER(_Phase), C.POINTER(C.c_int)]
+    L.eo_phase_free.argtypes = [C.POINTER(_Phase)]
+    L.eo_phase_obj.restype = C.c_double
+    L.eo_phase_obj.argtypes = [C.POINTER(_Phase)]
+    L.eo_phase_dual_obj.restype = C.c_double
+    L.eo_phase_dual_obj.argtypes = [C.POINTER(_Phase)]
+    common = [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+              C.c_int64]
+    tail = [C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    L.eo_primal_solve_with_initial.restype = C.c_int
+    L.eo_primal_solve_with_initial.argtypes = common + tail
+    L.eo_dual_solve_with_initial.restype = C.c_int
+    L.eo_dual_solve_with_initial.argtypes = common + [C.c_void_p, C.c_void_p] + tail
+    L.eo_solve.restype = C.c_int
+    L.eo_solve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(_Result)]
+    L.eo_result_free.argtypes = [C.POINTER(_Result)]
+    L.eo_synth_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Problem:
+    """Mirror of ellp::Problem for the oracle (problem.rs:12-154)."""
+
+    def __init__(self):
+        self._h = lib().eo_problem_new()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().eo_problem_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def add_var(self, obj, bound):
+        kind, lb, ub = bound
+        k = KIND[kind] if isinstance(kind, str) else int(kind)
+        if k == KIND["Fixed"]:
+            ub = lb
+        vid = lib().eo_add_var(self._h, float(obj), k, float(lb), float(ub))
+        if vid < 0:
+            raise ValueError("invalid variable")
+        return vid
+
+    def add_constraint(self, coeffs, op, rhs):
+        ids = np.asarray([c[0] for c in coeffs], dtype=np.int64)
+        cf = np.asarray([c[1] for c in coeffs], dtype=np.float64)
+        o = OP[op] if isinstance(op, str) else int(op)
+        rc = lib().eo_add_constraint(self._h, len(coeffs), _ptr(ids), _ptr(cf), o, float(rhs))
+        if rc != 0:
+            raise ValueError("invalid variable id in constraint")
+
+    def add_dense_constraints(self, A, op, b):
+        """rows of a dense matrix (used by the synthetic family)."""
+        A = np.asarray(A, dtype=np.float64)
+        ids = np.arange(A.shape[1], dtype=np.int64)
+        o = OP[op] if isinstance(op, str) else int(op)
+        for i in range(A.shape[0]):
+            row = np.ascontiguousarray(A[i])
+            lib().eo_add_constraint(self._h, A.shape[1], _ptr(ids), _ptr(row), o, float(b[i]))
+
+    @property
+    def num_vars(self):
+        return lib().eo_num_vars(self._h)
+
+    @staticmethod
+    def from_fixture(fx):
+        p = Problem()
+        for obj, bound in fx["vars"]:
+            p.add_var(obj, bound)
+        for coeffs, op, rhs in fx["constraints"]:
+            p.add_constraint(coeffs, op, rhs)
+        return p
+
+
+class Phase:
+    """Flat (C-ABI shaped) view of a standardized problem + feasible point (copies)."""
+
+    FIELDS = ("A", "c", "b", "kind", "lb", "ub", "x", "B", "N", "Nb", "y", "d")
+
+    def __init__(self, ph):
+        s = ph.contents
+        self.m, self.n, self.n_c = s.m, s.n, s.n_c
+        self.nB, self.nN = s.nB, s.nN
+        self.which = s.which
+        self.n_orig_vars = s.n_orig_vars
+
+        def arr(p, n, dt):
+            if not p or n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True)
+
+        self.A = arr(s.A, s.m * s.n, np.float64)  # column-major, ld = m
+        self.c = arr(s.c, s.n_c, np.float64)
+        self.b = arr(s.b, s.m, np.float64)
+        self.kind = arr(s.kind, s.n_c, np.uint8)
+        self.lb = arr(s.lb, s.n_c, np.float64)
+        self.ub = arr(s.ub, s.n_c, np.float64)
+        self.x = arr(s.x, s.n_c, np.float64)
+        self.B = arr(s.B, s.nB, np.int64)
+        # N gets head-room: the m == 0 trivial path rewrites it with up to n_c entries
+        self.N = np.zeros(max(s.nN, s.n_c), dtype=np.int64)
+        self.N[:s.nN] = arr(s.N, s.nN, np.int64)
+        self.Nb = np.zeros(max(s.nN, s.n_c), dtype=np.uint8)
+        self.Nb[:s.nN] = arr(s.Nb, s.nN, np.uint8)
+        self.y = arr(s.y, s.m, np.float64) if s.y else None
+        self.d = arr(s.d, s.n_c, np.float64) if s.d else None
+
+    def copy(self):
+        import copy
+        return copy.deepcopy(self)
+
+    def A_matrix(self):
+        return self.A.reshape((self.n, self.m)).T if self.m * self.n else np.zeros((self.m, self.n))
+
+    def obj(self):
+        return float(np.dot(self.c, self.x))
+
+
+class PhaseHandle:
+    """Owns an eo_phase*."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __bool__(self):
+        return bool(self.ptr)
+
+    def view(self):
+        return Phase(self.ptr)
+
+    def obj(self):
+        return lib().eo_phase_obj(self.ptr)
+
+    def dual_obj(self):
+        return lib().eo_phase_dual_obj(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().eo_phase_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def primal_phase1(prob):
+    err = C.c_int(0)
+    p = lib().eo_primal_phase1(prob._h, C.byref(err))
+    return (PhaseHandle(p) if p else None), err.value
+
+
+def primal_phase2(ph1):
+    return PhaseHandle(lib().eo_primal_phase2(ph1.ptr))
+
+
+def dual_phase1(prob):
+    err = C.c_int(0)
+    p = lib().eo_dual_phase1(prob._h, C.byref(err))
+    return (PhaseHandle(p) if p else None), err.value
+
+
+def dual_phase2(ph1):
+    err = C.c_int(0)
+    p = lib().eo_dual_phase2(ph1.ptr, C.byref(err))
+    return (PhaseHandle(p) if p else None), err.value
+
+
+def primal_solve_with_initial(ph, max_iter=MAX_ITER_NONE):
+    """Runs the oracle's primal loop on a Phase view IN PLACE. Returns (status, iters, err)."""
+    it = C.c_uint64(0)
+    err = C.create_string_buffer(256)
+    st = lib().eo_primal_solve_with_initial(
+        ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
+        _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
+        max_iter, C.byref(it), err, 256)
+    return st, it.value, err.value.decode()
+
+
+def dual_solve_with_initial(ph, max_iter=MAX_ITER_NONE):
+    it = C.c_uint64(0)
+    err = C.create_string_buffer(256)
+    st = lib().eo_dual_solve_with_initial(
+        ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
+        _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
+        _ptr(ph.y), _ptr(ph.d), max_iter, C.byref(it), err, 256)
+    return st, it.value, err.value.decode()
+
+
+class Result:
+    def __init__(self, r):
+        self.status = r.status
+        self.obj = r.obj
+        self.x = (np.ctypeslib.as_array(r.x, shape=(r.nx,)).copy()
+                  if (r.status == OPTIMAL and r.x and r.nx > 0) else np.zeros(0))
+        self.iters = (r.iters1, r.iters2)
+        self.err = r.err.decode()
+
+    def __repr__(self):
+        return f"Result(status={self.status}, obj={self.obj}, x={self.x}, iters={self.iters})"
+
+
+def solve(prob, solver="primal", max_iter=1000):
+    """PrimalSimplexSolver / DualSimplexSolver ::solve; default max_iter 1000 as Default."""
+    r = _Result()
+    lib().eo_solve(prob._h, 0 if solver == "primal" else 1,
+                   MAX_ITER_NONE if max_iter is None else int(max_iter), C.byref(r))
+    out = Result(r)
+    lib().eo_result_free(C.byref(r))
+    return out
+
+
+def synth_dense_lp(seed, m, n):
+    """SURVEY §8d family: returns (A (m x n, Fortran order), b, c)."""
+    A = np.zeros((m, n), dtype=np.float64, order="F")
+    b = np.zeros(m)
+    c = np.zeros(n)
+    lib().eo_synth_dense_lp(int(seed), m, n, _ptr(A), _ptr(b), _ptr(c))
+    return A, b, c
+
+
+def synth_problem(seed, m, n):
+    A, b, c = synth_dense_lp(seed, m, n)
+    p = Problem()
+    for j in range(n):
+        p.add_var(c[j], ("Lower", 0.0, 0.0))
+    p.add_dense_constraints(A, "Lte", b)
+    return p

@@ -1,0 +1,102 @@
+"""Shared test helpers: fixtures, a small MPS reader (data loader for the netlib fixtures),
+result checks written the way the reference's test macros are (tests/problems/mod.rs:9-71)."""
+import json
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def known_answers():
+    with open(os.path.join(GOLDEN, "known_answers.json")) as f:
+        return json.load(f)
+
+
+def read_mps(path):
+    """Free-format MPS subset the reference accepts (src/parse_mps.rs:23-546): NAME, ROWS,
+    COLUMNS (one entry per line), RHS, BOUNDS (UP/LO/FR), ENDATA.  Variables and rows are kept
+    in FILE order (the reference iterates HashMaps, so its order is random per process and its
+    tests pin the objective only).  Returns a fixture dict like known_answers.json's."""
+    rows, row_order, cols, col_order = {}, [], {}, []
+    section = None
+    with open(path) as f:
+        for raw in f:
+            if not raw.strip():
+                continue
+            tok = raw.split()
+            if raw[0] not in " \t":
+                section = tok[0]
+                if section == "ENDATA":
+                    break
+                continue
+            if section == "ROWS":
+                kind, name = tok
+                rows[name] = {"kind": kind, "coeffs": {}, "rhs": None}
+                row_order.append(name)
+            elif section == "COLUMNS":
+                var, row, val = tok
+                if var not in cols:
+                    cols[var] = {"obj": 0.0, "bound": None}
+                    col_order.append(var)
+                if rows[row]["kind"] == "N":
+                    cols[var]["obj"] = float(val)
+                else:
+                    assert var not in rows[row]["coeffs"]
+                    rows[row]["coeffs"][var] = float(val)
+            elif section == "RHS":
+                if len(tok) == 3:
+                    tok = tok[1:]
+                row, val = tok
+                assert rows[row]["kind"] != "N" and rows[row]["rhs"] is None
+                rows[row]["rhs"] = float(val)
+            elif section == "BOUNDS":
+                bt, col = tok[0], tok[2]
+                val = float(tok[3]) if len(tok) > 3 else None
+                cur = cols[col]["bound"]
+                if bt == "UP":
+                    new = ["Upper", 0.0, val]
+                elif bt == "LO":
+                    new = ["Lower", val, 0.0]
+                elif bt == "FR" and val is None:
+                    new = ["Free", 0.0, 0.0]
+                else:
+                    raise ValueError("invalid bound specification")
+                if cur is None:
+                    cols[col]["bound"] = new
+                elif cur[0] == "Upper" and new[0] == "Lower":
+                    cols[col]["bound"] = ["TwoSided", new[1], cur[2]]
+                elif cur[0] == "Lower" and new[0] == "Upper":
+                    cols[col]["bound"] = ["TwoSided", cur[1], new[2]]
+                else:
+                    raise ValueError("invalid bounds")
+    index = {v: i for i, v in enumerate(col_order)}
+    opmap = {"L": "Lte", "G": "Gte", "E": "Eq"}
+    fx = {"vars": [], "constraints": []}
+    for v in col_order:
+        fx["vars"].append([cols[v]["obj"], cols[v]["bound"] or ["Lower", 0.0, 0.0]])
+    for r in row_order:
+        if rows[r]["kind"] == "N":
+            continue
+        coeffs = [[index[v], c] for v, c in rows[r]["coeffs"].items()]
+        fx["constraints"].append([coeffs, opmap[rows[r]["kind"]], rows[r]["rhs"] or 0.0])
+    return fx
+
+
+def check_result(fx, status_name, obj, x, abs_eps=1e-8, rel_eps=1e-6):
+    """assert_optimal! / assert_optimal_obj! / assert_unbounded! / assert_infeasible!"""
+    chk = fx["check"]
+    if chk == "infeasible":
+        assert status_name == "infeasible", f"not infeasible: {status_name}"
+    elif chk == "unbounded":
+        assert status_name == "unbounded", f"not unbounded: {status_name}"
+    elif chk == "optimal":
+        assert status_name == "optimal", f"not optimal: {status_name}"
+        assert abs(obj - fx["obj"]) < abs_eps, f"obj: {obj}, expected: {fx['obj']}"
+        assert len(x) == len(fx["x"])
+        for a, b in zip(x, fx["x"]):
+            assert abs(a - b) < abs_eps, f"x_i: {a}, expected: {b}"
+    elif chk == "optimal_obj":
+        assert status_name == "optimal", f"not optimal: {status_name}"
+        e = fx["obj"]
+        assert abs(obj - e) < abs_eps or abs(obj / e - 1.0) < rel_eps, f"obj: {obj}, expected: {e}"
+    else:
+        raise AssertionError(chk)
