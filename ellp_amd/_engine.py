@@ -1,0 +1,216 @@
+"""ctypes binding of the C ABI in include/ellp_hip.h (libellp_hip.so).
+
+The library is the product's compute path; there is no Python or CPU substitute.  If it is
+missing or cannot be loaded this module raises — it never falls back.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libellp_hip.so")
+
+OPTIMAL, INFEASIBLE, UNBOUNDED, MAXITER = 0, 1, 2, 3
+ERR_BAD_DIMS, ERR_SINGULAR, ERR_NAN, ERR_DEVICE, ERR_ARG, ERR_PANIC = -1, -2, -3, -4, -5, -6
+STATUS_NAME = {0: "optimal", 1: "infeasible", 2: "unbounded", 3: "maxiter", -1: "err_bad_dims",
+               -2: "err_singular", -3: "err_nan", -4: "err_device", -5: "err_arg", -6: "err_panic"}
+MAX_ITER_NONE = 2**64 - 1
+ENGINE_PRIMAL, ENGINE_DUAL = 0, 1
+K_NAMES = ["price", "select", "ftran", "ratio", "update", "btran", "refactor", "dleave", "dprice",
+           "dselect", "dupdate", "_"]
+K_COUNT = 12
+TAP_U, TAP_R, TAP_D, TAP_BINV, TAP_KEY, TAP_ALPHA, TAP_RHO = range(7)
+
+
+class Opts(C.Structure):
+    _fields_ = [("max_iter", C.c_uint64), ("eps", C.c_double), ("device", C.c_int32),
+                ("refactor_period", C.c_int32), ("btran_mode", C.c_int32),
+                ("poll_interval", C.c_int32), ("profile", C.c_int32), ("use_graph", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iters", C.c_uint64), ("pivots", C.c_uint64), ("bound_flips", C.c_uint64),
+                ("refactors", C.c_uint64), ("obj", C.c_double), ("t_loop_s", C.c_double),
+                ("t_setup_s", C.c_double), ("kernel_ms", C.c_double * K_COUNT),
+                ("kernel_calls", C.c_uint64 * K_COUNT)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k in ("iters", "pivots", "bound_flips", "refactors", "obj",
+                                           "t_loop_s", "t_setup_s")}
+        d["kernel_ms"] = {K_NAMES[i]: self.kernel_ms[i] for i in range(K_COUNT) if self.kernel_calls[i]}
+        d["kernel_calls"] = {K_NAMES[i]: self.kernel_calls[i] for i in range(K_COUNT) if self.kernel_calls[i]}
+        return d
+
+
+class EllpHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"{STATUS_NAME.get(status, status)}: {msg}")
+        self.status = status
+        self.msg = msg
+
+
+_lib = None
+_PROBLEM_ARGS = [C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                 C.c_int64]
+
+
+def lib():
+    """Loads libellp_hip.so; raises if it is missing (build it with `python -m ellp_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP engine is the only compute path of ellp_amd. "
+            "Build it with `python -m ellp_amd.build` (hipcc --offload-arch=gfx950).")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L.ellp_default_opts.argtypes = [C.POINTER(Opts)]
+    L.ellp_hip_device_count.restype = C.c_int
+    L.ellp_hip_abi_version.restype = C.c_int
+    tail = [C.POINTER(Opts), C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    L.ellp_primal_solve_with_initial.restype = C.c_int
+    L.ellp_primal_solve_with_initial.argtypes = _PROBLEM_ARGS + tail
+    L.ellp_dual_solve_with_initial.restype = C.c_int
+    L.ellp_dual_solve_with_initial.argtypes = _PROBLEM_ARGS + [C.c_void_p, C.c_void_p] + tail
+    L.ellp_engine_create.restype = C.c_int
+    L.ellp_engine_create.argtypes = ([C.c_int] + _PROBLEM_ARGS + [C.c_void_p, C.c_void_p] +
+                                     [C.POINTER(Opts), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t])
+    L.ellp_engine_run.restype = C.c_int
+    L.ellp_engine_run.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    L.ellp_engine_read_point.restype = C.c_int
+    L.ellp_engine_read_point.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_char_p, C.c_size_t]
+    L.ellp_engine_tap.restype = C.c_int64
+    L.ellp_engine_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.ellp_engine_refactor.restype = C.c_int
+    L.ellp_engine_refactor.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_inverse_residual.restype = C.c_double
+    L.ellp_engine_inverse_residual.argtypes = [C.c_void_p]
+    L.ellp_engine_destroy.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def default_opts(**kw):
+    o = Opts()
+    lib().ellp_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if k == "max_iter" and v is None:
+            v = MAX_ITER_NONE
+        setattr(o, k, v)
+    return o
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class FlatProblem:
+    """The arrays solve_with_initial has in hand (standard_form.rs:21-34), C-ABI shaped.
+    A: (m*n,) column-major.  x/B/N/Nb (and y/d) are mutated in place by the solve calls."""
+
+    def __init__(self, m, n, n_c, A, c, b, kind, lb, ub, x, B, N, Nb, y=None, d=None, nN=None):
+        self.m, self.n, self.n_c = int(m), int(n), int(n_c)
+        self.A, self.c, self.b = _f64(A).reshape(-1), _f64(c), _f64(b)
+        self.kind = np.ascontiguousarray(kind, dtype=np.uint8)
+        self.lb, self.ub = _f64(lb), _f64(ub)
+        self.x = _f64(x).copy()
+        self.B = np.ascontiguousarray(B, dtype=np.int64).copy()
+        self.N = np.ascontiguousarray(N, dtype=np.int64).copy()
+        self.Nb = np.ascontiguousarray(Nb, dtype=np.uint8).copy()
+        self.nB = len(self.B)
+        self.nN = len(self.N) if nN is None else int(nN)
+        self.y = None if y is None else _f64(y).copy()
+        self.d = None if d is None else _f64(d).copy()
+
+    def _args(self):
+        return [self.m, self.n, self.n_c, _p(self.A), _p(self.c), _p(self.b), _p(self.kind),
+                _p(self.lb), _p(self.ub), _p(self.x), _p(self.B), self.nB, _p(self.N), _p(self.Nb),
+                self.nN]
+
+    def obj(self):
+        return float(np.dot(self.c, self.x))
+
+
+def primal_solve_with_initial(fp, opts=None):
+    """PrimalSimplexSolver::solve_with_initial on the GPU. Returns (status, Stats, errmsg)."""
+    o = opts or default_opts()
+    st = Stats()
+    err = C.create_string_buffer(512)
+    s = lib().ellp_primal_solve_with_initial(*fp._args(), C.byref(o), C.byref(st), err, 512)
+    return s, st, err.value.decode()
+
+
+def dual_solve_with_initial(fp, opts=None):
+    o = opts or default_opts()
+    st = Stats()
+    err = C.create_string_buffer(512)
+    s = lib().ellp_dual_solve_with_initial(*fp._args(), _p(fp.y), _p(fp.d), C.byref(o), C.byref(st),
+                                           err, 512)
+    return s, st, err.value.decode()
+
+
+class Engine:
+    """Resident engine: tableau stays in HBM between run() slices."""
+
+    def __init__(self, kind, fp, opts=None):
+        self.fp = fp
+        self.kind = kind
+        self._h = C.c_void_p()
+        o = opts or default_opts()
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_create(kind, *fp._args(), _p(fp.y), _p(fp.d), C.byref(o),
+                                     C.byref(self._h), err, 512)
+        if s != OPTIMAL:
+            self._h = C.c_void_p()
+            raise EllpHipError(s, err.value.decode())
+
+    def run(self, max_iters):
+        st = Stats()
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_run(self._h, int(max_iters), C.byref(st), err, 512)
+        if s == ERR_DEVICE:
+            raise EllpHipError(s, err.value.decode())
+        return s, st, err.value.decode()
+
+    def read_point(self):
+        fp = self.fp
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_read_point(self._h, _p(fp.x), _p(fp.B), _p(fp.N), _p(fp.Nb), _p(fp.y),
+                                         _p(fp.d), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+        return fp
+
+    def tap(self, what, count):
+        out = np.zeros(int(count), dtype=np.float64)
+        n = lib().ellp_engine_tap(self._h, what, _p(out), out.size)
+        if n < 0:
+            raise EllpHipError(int(n), "tap failed")
+        return out[:n]
+
+    def refactor(self):
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_refactor(self._h, err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def inverse_residual(self):
+        return lib().ellp_engine_inverse_residual(self._h)
+
+    def close(self):
+        if self._h:
+            lib().ellp_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,1714 @@
+// ellp_engine.hip — MI355X (gfx950) revised-simplex pivot engine behind include/ellp_hip.h.
+//
+// Replaces the loop bodies of kehlert/ellp 0.2.0
+//   src/solvers/primal/primal_simplex_solver.rs:160-235 (+ pivot() :238-435)
+//   src/solvers/dual/dual_simplex_solver.rs:188-334
+// with hand-written HIP kernels.  Where the reference re-factorises A_B by LU every iteration
+// (primal…:173, dual…:241) this engine keeps an explicit B^-1 resident in HBM, updates it by
+// a rank-1 (eta) update per pivot and re-derives it from A_B every `refactor_period`
+// iterations.  All decisions (entering, leaving, status) are taken on the device; the host
+// only enqueues launches and polls one status word every `poll_interval` iterations.
+//
+// Data layout in HBM (all f64, ld = round_up(m, 16) so every column/row starts 128-B aligned):
+//   A_N  : ld x n_N column-major  — nonbasic columns, physically swapped on a pivot exactly as
+//          the reference swaps them (primal…:211-217); pricing streams it once per iteration.
+//   A_B  : ld x m  column-major  — basic columns (only read by the refactorisation).
+//   W    : m x ld  ROW-major     — B^-1.  Row-major so that FTRAN (d_i = W[i,:].a_q) is one
+//          coalesced dot product per row, the dual's rho = row r of B^-1 is one contiguous
+//          copy, and the eta update streams whole rows.
+//   u, rho, d, x, c_B, c_N, keys : vectors.
+//
+// There is no CPU path in this file: without a HIP device every entry point returns
+// ELLP_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ellp_hip.h"
+
+namespace {
+
+constexpr int ST_RUNNING = 100;
+constexpr int WAVE = 64;
+
+struct DevState {
+    int32_t status;     // ST_RUNNING or an ellp_status
+    int32_t do_update;  // the ratio/dupdate kernel asks for an eta update of W
+    int32_t at_lower;   // entering variable sits at its lower bound (FTRAN result is negated)
+    int32_t side;       // bound the leaving variable goes to
+    int32_t nan_flag;
+    int32_t panic_code; // which assert of the reference fired
+    int64_t q;          // entering position in N
+    int64_t r;          // leaving position in B, -1 = none
+    int64_t refk;       // refactorisation step
+    double lambda;
+    double rq;          // reduced cost of the entering column
+    double d_r;         // d[r] (signed as stored in d)
+    double alpha_r;     // (B^-1 a_q)_r
+    double ucoef;       // rq / alpha_r : u += ucoef * rho
+    double delta, theta_d, theta_p, obj;  // dual
+    unsigned long long iters, pivots, flips;
+};
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ------------------------------------------------------------------ pricing
+// r_j = c_N[j] - A_N[:,j].u  for every nonbasic column (primal…:189), fused with the
+// eligibility filter / Dantzig key of pivot() (primal…:253-270).
+// MODE 1 (dual): alpha_j = A_N[:,j].rho (dual…:255) fused with the dual ratio key
+// d[N_j]/alpha_j over eligible columns (dual…:263-278) and a per-block first-argmin.
+//
+// One block = 256 threads = 4 waves streams `cpb` consecutive columns.  The 256 threads stride
+// down a column 16 B per lane (perfectly coalesced 4 KiB per block-instruction); the slice of
+// u each thread needs is loaded once into registers (T double2 per thread) and re-used for all
+// the block's columns; four columns are in flight at a time so every lane keeps 4*T 16-byte
+// loads outstanding.  HBM-bound: 8*ld bytes per column, 2 flops per 8 bytes.
+struct PriceArgs {
+    const double *A_N;
+    const double *u;      // primal: u ; dual: rho
+    const double *c_N;    // primal only
+    const uint8_t *Nb;
+    const int64_t *N_index;
+    const double *dd;     // dual: reduced costs d (indexed by variable)
+    double *r;            // primal: r ; dual: alpha
+    double *key;          // primal: Dantzig key (or -inf)
+    double *blockkey;     // per-block max (primal) / min (dual)
+    int64_t *blockpos;    // dual: position of the block's first minimum
+    DevState *st;
+    int64_t ld, nN;
+    int cpb;
+    double eps;
+};
+
+template <int T, int MODE>
+__global__ __launch_bounds__(256) void k_price(PriceArgs a) {
+    __shared__ double s_part[2][4][4];
+    __shared__ double s_k[4];
+    __shared__ long long s_p[4];
+    if (a.st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t half = a.ld >> 1;
+    const double2 *u2 = reinterpret_cast<const double2 *>(a.u);
+    double2 ur[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int64_t idx = tid + 256 * t;
+        ur[t] = idx < half ? u2[idx] : make_double2(0.0, 0.0);
+    }
+    const int64_t j0 = (int64_t)blockIdx.x * a.cpb;
+    const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
+    double sgn = 1.0;
+    if (MODE == 1) sgn = (a.st->delta < 0.0) ? -1.0 : 1.0;
+    double best = (MODE == 0) ? -INFINITY : INFINITY;
+    long long bestpos = -1;
+    int buf = 0;
+    for (int64_t j = j0; j < j1; j += 4, buf ^= 1) {
+        const int ncol = (int)((j1 - j) < 4 ? (j1 - j) : 4);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        const double2 *col[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t jj = (j + k < j1) ? j + k : j1 - 1;  // clamp: stay in bounds, no branch
+            col[k] = reinterpret_cast<const double2 *>(a.A_N + jj * a.ld);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t idx = tid + 256 * t;
+            if (idx < half) {
+                double2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = col[k][idx];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc[k] = fma(v[k].x, ur[t].x, acc[k]);
+                    acc[k] = fma(v[k].y, ur[t].y, acc[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_part[buf][wave][k] = acc[k];
+        }
+        __syncthreads();
+        if (tid < ncol) {
+            const int k = tid;
+            const double dot =
+                ((s_part[buf][0][k] + s_part[buf][1][k]) + s_part[buf][2][k]) + s_part[buf][3][k];
+            const int64_t jj = j + k;
+            const int nb = a.Nb[jj];
+            if (MODE == 0) {
+                const double rj = a.c_N[jj] - dot;
+                double key = -INFINITY;
+                if (rj != rj) {
+                    a.st->nan_flag = 1;
+                } else if (!(fabs(rj) < a.eps)) {
+                    const bool pos = rj > 0.0;
+                    if (pos && nb == ELLP_NB_UPPER) key = rj;
+                    else if (!pos && nb == ELLP_NB_LOWER) key = -rj;
+                    else if (nb == ELLP_NB_FREE) key = fabs(rj);
+                }
+                a.r[jj] = rj;
+                a.key[jj] = key;
+                best = fmax(best, key);
+            } else {
+                a.r[jj] = dot;  // alpha (un-negated, dual…:286-288 restores the sign anyway)
+                const double al = sgn * dot;
+                bool keep;
+                if (nb == ELLP_NB_LOWER) keep = al > a.eps;
+                else if (nb == ELLP_NB_UPPER) keep = al < -a.eps;
+                else keep = true;
+                if (keep) {
+                    const double ratio = a.dd[a.N_index[jj]] / al;
+                    if (ratio != ratio) a.st->nan_flag = 1;
+                    if (bestpos < 0 || ratio < best) {  // strict '<' keeps the FIRST minimum
+                        best = ratio;
+                        bestpos = jj;
+                    }
+                }
+            }
+        }
+    }
+    // combine the (up to) four column-owner threads; they all live in wave 0
+    if (MODE == 0) {
+        if (wave == 0) {
+            double v = (lane < 4) ? best : -INFINITY;
+            v = fmax(v, __shfl_xor(v, 1));
+            v = fmax(v, __shfl_xor(v, 2));
+            if (lane == 0) a.blockkey[blockIdx.x] = v;
+        }
+    } else {
+        if (tid < 4) {
+            s_k[tid] = best;
+            s_p[tid] = bestpos;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double bk = INFINITY;
+            long long bp = -1;
+            for (int k = 0; k < 4; ++k) {
+                if (s_p[k] < 0) continue;
+                if (bp < 0 || s_k[k] < bk || (s_k[k] == bk && s_p[k] < bp)) {
+                    bk = s_k[k];
+                    bp = s_p[k];
+                }
+            }
+            a.blockkey[blockIdx.x] = bk;
+            a.blockpos[blockIdx.x] = bp;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ primal entering selection
+// Exact emulation of the reference's sequential `max_by` fold (primal…:271-287): candidate
+// (key, N.index) replaces the accumulator iff NOT(|acc-key| >= EPS ? acc > key : acc.index >
+// index).  The comparator is not transitive, so the fold cannot be turned into a tree
+// reduction; instead ONE wave walks the pricing blocks in position order and uses ballots to
+// skip everything that cannot change the accumulator: a block whose maximum key is
+// <= acc - EPS holds no such element.  Work is O(#blocks/64 + #accumulator changes).
+struct SelectArgs {
+    const double *key, *blockkey, *r;
+    const int64_t *N_index;
+    const uint8_t *Nb;
+    DevState *st;
+    int64_t nN;
+    int nblocks, cpb;
+    double eps;
+};
+
+__global__ __launch_bounds__(64) void k_select(SelectArgs a) {
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int lane = threadIdx.x;
+    if (st->nan_flag) {
+        if (lane == 0) st->status = ELLP_ERR_NAN;
+        return;
+    }
+    bool have = false;
+    double racc = 0.0;
+    long long iacc = 0, qacc = -1;
+    for (int g0 = 0; g0 < a.nblocks; g0 += WAVE) {
+        const double bm = (g0 + lane < a.nblocks) ? a.blockkey[g0 + lane] : -INFINITY;
+        int from = 0;
+        for (;;) {
+            const bool pred = lane >= from && bm > -INFINITY && (!have || bm > racc - a.eps);
+            const unsigned long long mask = __ballot(pred);
+            if (!mask) break;
+            const int bl = __ffsll((long long)mask) - 1;
+            const int64_t jb = (int64_t)(g0 + bl) * a.cpb;
+            const int64_t j = jb + lane;
+            const bool valid = lane < a.cpb && j < a.nN;
+            const double k = valid ? a.key[j] : -INFINITY;
+            const long long idx = valid ? a.N_index[j] : 0;
+            int efrom = 0;
+            for (;;) {
+                bool ev = lane >= efrom && k > -INFINITY;
+                if (ev && have) {
+                    const bool acc_greater = (fabs(racc - k) >= a.eps) ? (racc > k) : (iacc > idx);
+                    ev = !acc_greater;
+                }
+                const unsigned long long em = __ballot(ev);
+                if (!em) break;
+                const int l = __ffsll((long long)em) - 1;
+                racc = __shfl(k, l);
+                iacc = __shfl(idx, l);
+                qacc = jb + l;
+                have = true;
+                efrom = l + 1;
+            }
+            from = bl + 1;
+        }
+    }
+    if (lane == 0) {
+        st->do_update = 0;
+        if (!have) {
+            st->iters += 1;
+            st->status = ELLP_OPTIMAL;  // primal…:289-292
+        } else {
+            st->q = qacc;
+            st->rq = a.r[qacc];
+            st->at_lower = (a.Nb[qacc] == ELLP_NB_LOWER) ? 1 : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ FTRAN
+// d = +-B^-1 a_q (primal…:295-300, dual…:294): one wave per row of the row-major W, 16 B per
+// lane, a_q re-read through L1/L2 (it is 8*ld bytes, W is 8*m*ld).  mode 0: column q of A_N,
+// sign from st->at_lower.  mode 1 (refactorisation): column st->refk of A_B, sign +.
+struct FtranArgs {
+    const double *W;
+    const double *A_N, *A_B;
+    double *d;
+    DevState *st;
+    int64_t m, ld;
+    int mode;
+};
+
+__global__ __launch_bounds__(256) void k_ftran(FtranArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t half = a.ld >> 1;
+    const double2 *col;
+    double sgn = 1.0;
+    if (a.mode == 0) {
+        col = reinterpret_cast<const double2 *>(a.A_N + a.st->q * a.ld);
+        sgn = a.st->at_lower ? -1.0 : 1.0;
+    } else {
+        col = reinterpret_cast<const double2 *>(a.A_B + a.st->refk * a.ld);
+    }
+    for (int64_t i = wave_global; i < a.m; i += nwaves) {
+        const double2 *row = reinterpret_cast<const double2 *>(a.W + i * a.ld);
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 4
+        for (int64_t t = lane; t < half; t += WAVE) {
+            const double2 w = row[t];
+            const double2 c = col[t];
+            acc0 = fma(w.x, c.x, acc0);
+            acc1 = fma(w.y, c.y, acc1);
+        }
+        const double s = wave_sum(acc0 + acc1);
+        if (lane == 0) a.d[i] = sgn * s;
+    }
+}
+
+// ------------------------------------------------------------------ primal ratio test + pivot bookkeeping
+// One 1024-thread block.  Phase A (all waves): lambda_i per basic row by bound kind
+// (primal…:320-367) into LDS (or a global scratch when m is too large) + per-64 minima.
+// Phase B (wave 0): exact emulation of the sequential fold (primal…:379-399), including the
+// quirk that `new_basic_index` is only written in the tie branch; ballots skip every chunk
+// whose minimum cannot touch the running lambda.  Phase C (all waves): x update
+// (primal…:408-417), index / column / cost swap (primal…:205-221) or bound flip (:223-231),
+// and a copy of row r of B^-1 (rho) for the eta update.
+struct RatioArgs {
+    double *W, *A_N, *A_B, *c_B, *c_N, *x, *d, *rho;
+    const double *lb, *ub;
+    const uint8_t *kind;
+    int64_t *B_index, *N_index;
+    uint8_t *Nb;
+    double *g_lam;     // global scratch (m) when LDS is too small
+    int32_t *g_bidx;
+    uint8_t *g_dpos;
+    DevState *st;
+    int64_t m, ld;
+    int use_lds;
+    double eps;
+};
+
+__global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_lambda;
+    __shared__ long long s_nb;
+    __shared__ int s_side;
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m = a.m;
+    const int nchunks = (int)((m + 63) >> 6);
+    double *chunkmin = reinterpret_cast<double *>(smem);
+    double *lam;
+    int32_t *bidx;
+    uint8_t *dpos;
+    if (a.use_lds) {
+        lam = chunkmin + nchunks;
+        bidx = reinterpret_cast<int32_t *>(lam + m);
+        dpos = reinterpret_cast<uint8_t *>(bidx + m);
+    } else {
+        lam = a.g_lam;
+        bidx = a.g_bidx;
+        dpos = a.g_dpos;
+    }
+    const int64_t q = st->q;
+    const int64_t jq = a.N_index[q];
+    const int at_lower = st->at_lower;
+    const double eps = a.eps;
+
+    // ---- phase A
+    for (int c = wave; c < nchunks; c += 16) {
+        const int64_t i = (int64_t)c * 64 + lane;
+        double li = INFINITY;
+        int32_t bi = 0;
+        bool dp = false;
+        if (i < m) {
+            const double di = a.d[i];
+            bi = (int32_t)a.B_index[i];
+            dp = di > 0.0;
+            if (!(fabs(di) < eps)) {
+                const double xi = a.x[bi];
+                const int k = a.kind[bi];
+                const double lbi = a.lb[bi], ubi = a.ub[bi];
+                if (k == ELLP_BOUND_FREE) {
+                    li = INFINITY;
+                } else if (k == ELLP_BOUND_LOWER) {
+                    if (di > 0.0) li = INFINITY;
+                    else if (xi > lbi) li = (lbi - xi) / di;
+                    else li = 0.0;
+                } else if (k == ELLP_BOUND_UPPER) {
+                    if (di > 0.0) li = (xi < ubi) ? (ubi - xi) / di : 0.0;
+                    else li = INFINITY;
+                } else if (k == ELLP_BOUND_TWOSIDED) {
+                    if (di > 0.0) li = (xi < ubi) ? (ubi - xi) / di : 0.0;
+                    else if (xi < lbi) li = (lbi - xi) / di;  // quirk Q1 (primal…:359)
+                    else li = 0.0;
+                } else {
+                    li = 0.0;  // Fixed
+                }
+                if (li != li) st->nan_flag = 1;
+            }
+            lam[i] = li;
+            bidx[i] = bi;
+            dpos[i] = dp ? 1 : 0;
+        }
+        const double cm = wave_min(li);
+        if (lane == 0) chunkmin[c] = cm;
+    }
+    __syncthreads();
+
+    // ---- phase B
+    if (wave == 0) {
+        double lambda;
+        {
+            const int k = a.kind[jq];
+            if (k == ELLP_BOUND_TWOSIDED) lambda = a.ub[jq] - a.lb[jq];
+            else if (k == ELLP_BOUND_FIXED) lambda = 0.0;
+            else lambda = INFINITY;
+        }
+        long long nb = -1;
+        int side = ELLP_NB_LOWER;
+        bool have_nbi = false;
+        int32_t nbi = 0;
+        for (int g0 = 0; g0 < nchunks; g0 += WAVE) {
+            const double cm = (g0 + lane < nchunks) ? chunkmin[g0 + lane] : INFINITY;
+            int from = 0;
+            for (;;) {
+                const bool pred = lane >= from && cm < lambda + eps;
+                const unsigned long long mask = __ballot(pred);
+                if (!mask) break;
+                const int cl = __ffsll((long long)mask) - 1;
+                const int64_t i = (int64_t)(g0 + cl) * 64 + lane;
+                const double li = (i < m) ? lam[i] : INFINITY;
+                const int32_t bi = (i < m) ? bidx[i] : 0;
+                const int dp = (i < m) ? dpos[i] : 0;
+                int efrom = 0;
+                for (;;) {
+                    const bool strict = li < lambda - eps;
+                    const bool tie = !strict && fabs(li - lambda) < eps && (!have_nbi || bi < nbi);
+                    const bool ev = lane >= efrom && (strict || tie);
+                    const unsigned long long em = __ballot(ev);
+                    if (!em) break;
+                    const int l = __ffsll((long long)em) - 1;
+                    const int was_tie = __shfl((int)tie, l);
+                    lambda = __shfl(li, l);
+                    nb = (long long)(g0 + cl) * 64 + l;
+                    side = __shfl(dp, l) ? ELLP_NB_UPPER : ELLP_NB_LOWER;
+                    if (was_tie) {
+                        have_nbi = true;
+                        nbi = __shfl(bi, l);
+                    }
+                    efrom = l + 1;
+                }
+                from = cl + 1;
+            }
+        }
+        if (lane == 0) {
+            s_lambda = lambda;
+            s_nb = nb;
+            s_side = side;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C
+    const double lambda = s_lambda;
+    const long long nbp = s_nb;
+    if (st->nan_flag) {
+        if (tid == 0) st->status = ELLP_ERR_NAN;
+        return;
+    }
+    if (!(lambda >= 0.0)) {  // primal…:402
+        if (tid == 0) {
+            st->panic_code = 402;
+            st->status = ELLP_ERR_PANIC;
+        }
+        return;
+    }
+    if (isinf(lambda)) {  // primal…:404-406
+        if (tid == 0) {
+            st->iters += 1;
+            st->status = ELLP_UNBOUNDED;
+        }
+        return;
+    }
+    if (lambda > 0.0) {
+        for (int64_t i = tid; i < m; i += 1024) {
+            const int64_t bi = a.B_index[i];
+            a.x[bi] = a.x[bi] + lambda * a.d[i];
+        }
+        if (tid == 0) {
+            if (at_lower) a.x[jq] = a.x[jq] + lambda;
+            else a.x[jq] = a.x[jq] - lambda;
+        }
+    }
+    __syncthreads();
+    if (nbp >= 0) {
+        const int64_t r = nbp;
+        for (int64_t j = tid; j < a.ld; j += 1024) {
+            a.rho[j] = a.W[r * a.ld + j];
+            const double t = a.A_N[q * a.ld + j];
+            a.A_N[q * a.ld + j] = a.A_B[r * a.ld + j];
+            a.A_B[r * a.ld + j] = t;
+        }
+        if (tid == 0) {
+            const double tc = a.c_N[q];
+            a.c_N[q] = a.c_B[r];
+            a.c_B[r] = tc;
+            const int64_t ti = a.B_index[r];
+            a.B_index[r] = a.N_index[q];
+            a.N_index[q] = ti;
+            a.Nb[q] = (uint8_t)s_side;
+            const double dr = a.d[r];
+            const double alpha_r = at_lower ? -dr : dr;
+            st->r = r;
+            st->side = s_side;
+            st->lambda = lambda;
+            st->d_r = dr;
+            st->alpha_r = alpha_r;
+            st->ucoef = st->rq / alpha_r;
+            st->do_update = 1;
+            st->pivots += 1;
+            st->iters += 1;
+        }
+    } else {
+        if (tid == 0) {
+            const int nbq = a.Nb[q];
+            st->r = -1;
+            st->lambda = lambda;
+            st->do_update = 0;
+            if (nbq == ELLP_NB_LOWER) a.Nb[q] = ELLP_NB_UPPER;
+            else if (nbq == ELLP_NB_UPPER) a.Nb[q] = ELLP_NB_LOWER;
+            else {
+                st->panic_code = 229;  // "pivot should have been unbounded"
+                st->status = ELLP_ERR_PANIC;
+            }
+            st->flips += 1;
+            st->iters += 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ eta update of B^-1
+// W[i,:] -= (d_i/d_r) * rho   (i != r),   W[r,:] = rho / alpha_r.   16*m*ld bytes (read+write),
+// rows with d_i == 0 are untouched.  The last block also carries the O(m) BTRAN update
+// u += (r_q/alpha_r) * rho when the engine runs in incremental-u mode.
+struct UpdateArgs {
+    double *W;
+    const double *d, *rho;
+    double *u;
+    DevState *st;
+    int64_t m, ld;
+    int rows_per_block;
+    int update_u;
+};
+
+__global__ __launch_bounds__(256) void k_update(UpdateArgs a) {
+    const DevState *st = a.st;
+    if (st->status != ST_RUNNING || !st->do_update) return;
+    const int tid = threadIdx.x;
+    const int64_t half = a.ld >> 1;
+    const int64_t r = st->r;
+    const double d_r = st->d_r, alpha_r = st->alpha_r;
+    const double2 *rho2 = reinterpret_cast<const double2 *>(a.rho);
+    for (int rr = 0; rr < a.rows_per_block; ++rr) {
+        const int64_t i = (int64_t)blockIdx.x * a.rows_per_block + rr;
+        if (i >= a.m) break;
+        double2 *row = reinterpret_cast<double2 *>(a.W + i * a.ld);
+        if (i == r) {
+            for (int64_t t = tid; t < half; t += 256) {
+                const double2 p = rho2[t];
+                row[t] = make_double2(p.x / alpha_r, p.y / alpha_r);
+            }
+        } else {
+            const double di = a.d[i];
+            if (di == 0.0) continue;
+            const double f = -(di / d_r);
+            for (int64_t t = tid; t < half; t += 256) {
+                const double2 p = rho2[t];
+                double2 w = row[t];
+                w.x = fma(f, p.x, w.x);
+                w.y = fma(f, p.y, w.y);
+                row[t] = w;
+            }
+        }
+    }
+    if (a.update_u && blockIdx.x == gridDim.x - 1) {
+        const double cf = st->ucoef;
+        double2 *u2 = reinterpret_cast<double2 *>(a.u);
+        for (int64_t t = tid; t < half; t += 256) {
+            const double2 p = rho2[t];
+            double2 w = u2[t];
+            w.x = fma(cf, p.x, w.x);
+            w.y = fma(cf, p.y, w.y);
+            u2[t] = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BTRAN  u = B^-T c_B  (primal…:184-187)
+// u_j = sum_i c_B[i] * W[i][j].  grid (col tiles of 512, row tiles): partial sums per row tile
+// then a fixed-order reduction — deterministic, no atomics.  Rows with c_B[i] == 0 are skipped
+// (phase 1: only artificial basics carry cost).
+struct BtranArgs {
+    const double *W, *c_B;
+    double *upart, *u;
+    DevState *st;
+    int64_t m, ld;
+    int rows_per_tile, ntiles;
+};
+
+__global__ __launch_bounds__(256) void k_btran_part(BtranArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int64_t half = a.ld >> 1;
+    const int64_t j2 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * a.rows_per_tile;
+    const int64_t i1 = (i0 + a.rows_per_tile < a.m) ? i0 + a.rows_per_tile : a.m;
+    double2 acc = make_double2(0.0, 0.0);
+    if (j2 < half) {
+        const double2 *W2 = reinterpret_cast<const double2 *>(a.W);
+        for (int64_t i = i0; i < i1; ++i) {
+            const double ci = a.c_B[i];
+            if (ci != 0.0) {
+                const double2 w = W2[i * half + j2];
+                acc.x = fma(ci, w.x, acc.x);
+                acc.y = fma(ci, w.y, acc.y);
+            }
+        }
+        reinterpret_cast<double2 *>(a.upart)[(int64_t)blockIdx.y * half + j2] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.ld) return;
+    double s = 0.0;
+    for (int t = 0; t < a.ntiles; ++t) s += a.upart[(int64_t)t * a.ld + j];
+    a.u[j] = s;
+}
+
+// ------------------------------------------------------------------ refactorisation of B^-1 from A_B
+// Product-form rebuild with partial pivoting: start from W = I and bring the m basic columns
+// in one at a time: alpha = W a_k (k_ftran mode 1), pivot row p = first max |alpha_i| over the
+// rows not used yet (the same pivot partial-pivot LU takes, primal…:173), eta update with row
+// p.  The pivot magnitudes are LU's U_kk, so the reference's singularity guard
+// (any |U_ii| < EPS, primal…:175-179) is checked on them.  Afterwards rows are permuted so that
+// row k belongs to basic position k.
+struct RefArgs {
+    double *W, *W2, *d, *rho;
+    int32_t *used;
+    int64_t *perm;
+    DevState *st;
+    int64_t m, ld;
+    double eps;
+};
+
+__global__ __launch_bounds__(256) void k_ref_init(RefArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int64_t total = a.m * a.ld;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / a.ld, j = t - i * a.ld;
+        a.W[t] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.m; i += (int64_t)gridDim.x * 256) a.used[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.st->refk = 0;
+}
+
+__global__ __launch_bounds__(1024) void k_ref_pick(RefArgs a) {
+    __shared__ double s_v[16];
+    __shared__ long long s_i[16];
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double bv = -1.0;
+    long long bi = -1;
+    for (int64_t i = tid; i < a.m; i += 1024) {
+        if (a.used[i]) continue;
+        const double v = fabs(a.d[i]);
+        if (v > bv) {  // strict: first maximum within this thread's increasing i
+            bv = v;
+            bi = i;
+        }
+    }
+    // lexicographic (max value, min index) — associative, so a tree is exact
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o);
+        const long long oi = __shfl_xor(bi, o);
+        if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) {
+            if (s_i[w] >= 0 && (bi < 0 || s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi))) {
+                bv = s_v[w];
+                bi = s_i[w];
+            }
+        }
+        s_i[0] = bi;
+        s_v[0] = bv;
+    }
+    __syncthreads();
+    const long long p = s_i[0];
+    const double pv = s_v[0];
+    if (p < 0 || pv < a.eps || pv != pv) {
+        if (tid == 0) st->status = ELLP_ERR_SINGULAR;
+        return;
+    }
+    for (int64_t j = tid; j < a.ld; j += 1024) a.rho[j] = a.W[p * a.ld + j];
+    if (tid == 0) {
+        a.used[p] = 1;
+        a.perm[st->refk] = p;
+        st->r = p;
+        st->d_r = a.d[p];
+        st->alpha_r = a.d[p];
+        st->do_update = 1;
+        st->refk += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ref_permute(RefArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int64_t k = blockIdx.x;
+    const int64_t p = a.perm[k];
+    const double2 *src = reinterpret_cast<const double2 *>(a.W + p * a.ld);
+    double2 *dst = reinterpret_cast<double2 *>(a.W2 + k * a.ld);
+    for (int64_t t = threadIdx.x; t < (a.ld >> 1); t += 256) dst[t] = src[t];
+    if (k == 0 && threadIdx.x == 0) a.st->do_update = 0;
+}
+
+// max |W A_B - I| (drift monitor, test/diagnostic only — m^3 work)
+__global__ __launch_bounds__(256) void k_inv_residual(const double *W, const double *A_B, int64_t m, int64_t ld,
+                                                      double *out) {
+    __shared__ double s_m[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x;
+    const double2 *row = reinterpret_cast<const double2 *>(W + i * ld);
+    double worst = 0.0;
+    for (int64_t k = wave; k < m; k += 4) {
+        const double2 *col = reinterpret_cast<const double2 *>(A_B + k * ld);
+        double acc = 0.0;
+        for (int64_t t = lane; t < (ld >> 1); t += WAVE) {
+            const double2 w = row[t], c = col[t];
+            acc = fma(w.x, c.x, acc);
+            acc = fma(w.y, c.y, acc);
+        }
+        acc = wave_sum(acc);
+        const double e = fabs(acc - (i == k ? 1.0 : 0.0));
+        worst = fmax(worst, e);
+    }
+    if (lane == 0) s_m[wave] = worst;
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
+}
+
+// ------------------------------------------------------------------ dual kernels
+// leaving row: FIRST basic position (in B order) whose variable violates a bound by more than
+// EPS (dual…:200-236) — a min-position reduction, exact as a tree.  Also copies rho = row r of
+// B^-1 (dual…:248-253 obtains the same row by two triangular solves).
+struct DLeaveArgs {
+    const double *W, *x, *lb, *ub;
+    const uint8_t *kind;
+    const int64_t *B_index;
+    double *rho;
+    DevState *st;
+    int64_t m, ld;
+    double eps;
+};
+
+__device__ __forceinline__ bool dual_violation(const DLeaveArgs &a, int64_t i, double *delta, int *side) {
+    const int64_t bi = a.B_index[i];
+    const double xi = a.x[bi];
+    const int k = a.kind[bi];
+    if (k == ELLP_BOUND_LOWER) {
+        if (xi < a.lb[bi] - a.eps) { *delta = xi - a.lb[bi]; *side = ELLP_NB_LOWER; return true; }
+    } else if (k == ELLP_BOUND_UPPER) {
+        if (xi > a.ub[bi] + a.eps) { *delta = xi - a.ub[bi]; *side = ELLP_NB_UPPER; return true; }
+    } else if (k == ELLP_BOUND_TWOSIDED) {
+        if (xi > a.ub[bi] + a.eps) { *delta = xi - a.ub[bi]; *side = ELLP_NB_UPPER; return true; }
+        if (xi < a.lb[bi] - a.eps) { *delta = xi - a.lb[bi]; *side = ELLP_NB_LOWER; return true; }
+    }
+    return false;  // Free and Fixed basics never leave (quirk Q3)
+}
+
+__global__ __launch_bounds__(1024) void k_dleave(DLeaveArgs a) {
+    __shared__ long long s_i[16];
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long best = INT64_MAX;
+    double dl;
+    int sd;
+    for (int64_t i = tid; i < a.m; i += 1024) {
+        if (dual_violation(a, i, &dl, &sd)) {
+            best = i;
+            break;  // increasing i per thread: the first hit is this thread's minimum
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long ob = __shfl_xor(best, o);
+        best = ob < best ? ob : best;
+    }
+    if (lane == 0) s_i[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) best = s_i[w] < best ? s_i[w] : best;
+        s_i[0] = best;
+    }
+    __syncthreads();
+    const long long r = s_i[0];
+    if (r == INT64_MAX) {
+        if (tid == 0) {
+            st->iters += 1;
+            st->status = ELLP_OPTIMAL;  // dual…:243-246
+        }
+        return;
+    }
+    for (int64_t j = tid; j < a.ld; j += 1024) a.rho[j] = a.W[r * a.ld + j];
+    if (tid == 0) {
+        double delta = 0.0;
+        int side = 0;
+        dual_violation(a, r, &delta, &side);
+        st->r = r;
+        st->delta = delta;
+        st->side = side;
+        st->do_update = 0;
+    }
+}
+
+// dual ratio argmin over the per-block minima (dual…:279: min_by keeps the FIRST minimum)
+struct DSelectArgs {
+    const double *blockkey;
+    const int64_t *blockpos;
+    DevState *st;
+    int nblocks;
+};
+__global__ __launch_bounds__(64) void k_dselect(DSelectArgs a) {
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int lane = threadIdx.x;
+    if (st->nan_flag) {
+        if (lane == 0) st->status = ELLP_ERR_NAN;
+        return;
+    }
+    double bk = INFINITY;
+    long long bp = -1;
+    for (int b = lane; b < a.nblocks; b += WAVE) {
+        const long long p = a.blockpos[b];
+        if (p < 0) continue;
+        const double k = a.blockkey[b];
+        if (bp < 0 || k < bk || (k == bk && p < bp)) {
+            bk = k;
+            bp = p;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ok = __shfl_xor(bk, o);
+        const long long op = __shfl_xor(bp, o);
+        if (op >= 0 && (bp < 0 || ok < bk || (ok == bk && op < bp))) {
+            bk = ok;
+            bp = op;
+        }
+    }
+    if (lane == 0) {
+        if (bp < 0) {
+            st->iters += 1;
+            st->status = ELLP_INFEASIBLE;  // dual unbounded, dual…:281-284
+        } else {
+            st->q = bp;
+            st->at_lower = 0;
+            st->theta_d = (st->delta < 0.0) ? -bk : bk;  // dual…:286-289
+        }
+    }
+}
+
+// d, y, x updates and the basis swap (dual…:296-333)
+struct DUpdateArgs {
+    double *A_N, *A_B, *c_B, *c_N, *x, *y, *dd;
+    const double *alpha, *alpha_q, *rho;
+    int64_t *B_index, *N_index;
+    uint8_t *Nb;
+    DevState *st;
+    int64_t m, ld, nN;
+};
+__global__ __launch_bounds__(1024) void k_dupdate(DUpdateArgs a) {
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x;
+    const int64_t q = st->q, r = st->r;
+    const double theta_d = st->theta_d, delta = st->delta;
+    const int64_t leaving_var = a.B_index[r];
+    const int64_t entering_var = a.N_index[q];
+    const double aqr = a.alpha_q[r];
+    const double theta_p = delta / aqr;
+    for (int64_t j = tid; j < a.nN; j += 1024) {
+        if (j == q) continue;
+        const int64_t v = a.N_index[j];
+        a.dd[v] = a.dd[v] - theta_d * a.alpha[j];
+    }
+    for (int64_t i = tid; i < a.m; i += 1024) {
+        a.y[i] = a.y[i] + theta_d * a.rho[i];
+        const int64_t bi = a.B_index[i];
+        a.x[bi] = a.x[bi] - theta_p * a.alpha_q[i];
+    }
+    __syncthreads();
+    for (int64_t j = tid; j < a.ld; j += 1024) {
+        const double t = a.A_N[q * a.ld + j];
+        a.A_N[q * a.ld + j] = a.A_B[r * a.ld + j];
+        a.A_B[r * a.ld + j] = t;
+    }
+    if (tid == 0) {
+        a.dd[leaving_var] = -theta_d;
+        a.dd[entering_var] = 0.0;
+        a.x[entering_var] = a.x[entering_var] + theta_p;
+        st->obj = st->obj + theta_d * delta;
+        st->theta_p = theta_p;
+        a.B_index[r] = entering_var;
+        a.N_index[q] = leaving_var;
+        a.Nb[q] = (uint8_t)st->side;
+        const double tc = a.c_N[q];
+        a.c_N[q] = a.c_B[r];
+        a.c_B[r] = tc;
+        st->d_r = aqr;
+        st->alpha_r = aqr;
+        st->do_update = 1;
+        st->pivots += 1;
+        st->iters += 1;
+        if (aqr != aqr || theta_p != theta_p) st->status = ELLP_ERR_NAN;
+    }
+}
+
+// gather columns of A (m x n, ld m) into a padded destination (ld) by an index list
+__global__ __launch_bounds__(256) void k_gather_cols(const double *A, int64_t m, const int64_t *index, double *dst,
+                                                     int64_t ld) {
+    const int64_t k = blockIdx.x;
+    const double *src = A + index[k] * m;
+    double *o = dst + k * ld;
+    for (int64_t i = threadIdx.x; i < ld; i += 256) o[i] = i < m ? src[i] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_gather_vec(const double *v, const int64_t *index, double *dst, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) dst[k] = v[index[k]];
+}
+
+}  // namespace
+
+// ====================================================================== host side
+
+struct ellp_engine {
+    int kind = 0;
+    int64_t m = 0, n = 0, n_c = 0, nN = 0, ld = 0;
+    double eps = 1e-10;
+    ellp_opts opts{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // device memory
+    double *A_B = nullptr, *A_N = nullptr, *W = nullptr, *W2 = nullptr;
+    double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *r = nullptr, *key = nullptr;
+    double *blockkey = nullptr, *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr, *rho = nullptr;
+    double *upart = nullptr, *y = nullptr, *dd = nullptr, *g_lam = nullptr, *resid = nullptr;
+    int64_t *blockpos = nullptr, *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
+    uint8_t *kindv = nullptr, *Nb = nullptr, *g_dpos = nullptr;
+    int32_t *used = nullptr, *g_bidx = nullptr;
+    DevState *st = nullptr;
+    DevState *h_st = nullptr;  // pinned
+    // launch geometry
+    int cpb = 1, nblocks = 1, priceT = 1;
+    int upd_rows = 2, upd_blocks = 1;
+    int ftran_blocks = 1;
+    int btran_tiles = 1, btran_rows = 1;
+    int ratio_use_lds = 1;
+    size_t ratio_lds = 0;
+    // loop bookkeeping
+    uint64_t since_refactor = 0, since_btran = 0;
+    int refactor_period = 0;
+    int btran_refresh = 32;
+    uint64_t refactors = 0;
+    bool u_valid = false;
+    double t_setup = 0.0;
+    // profiling
+    std::vector<hipEvent_t> ev_pool;
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    size_t ev_next = 0;
+    double kernel_ms[ELLP_K_COUNT] = {0};
+    uint64_t kernel_calls[ELLP_K_COUNT] = {0};
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+void set_err(char *errbuf, size_t len, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+void set_err(char *errbuf, size_t len, const char *fmt, ...) {
+    if (!errbuf || !len) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(errbuf, len, fmt, ap);
+    va_end(ap);
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            set_err(errbuf, errlen, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, \
+                    __LINE__, #expr);                                                             \
+            return ELLP_ERR_DEVICE;                                                               \
+        }                                                                                         \
+    } while (0)
+
+template <typename T>
+hipError_t dmalloc(ellp_engine *e, T **p, size_t count) {
+    void *q = nullptr;
+    hipError_t rc = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+    if (rc == hipSuccess) {
+        e->allocs.push_back(q);
+        *p = static_cast<T *>(q);
+    }
+    return rc;
+}
+
+inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Prof {
+    ellp_engine *e;
+    int id;
+    bool on;
+    hipEvent_t a{}, b{};
+    Prof(ellp_engine *e_, int id_) : e(e_), id(id_), on(e_->opts.profile != 0) {
+        if (!on) return;
+        if (e->ev_next + 2 > e->ev_pool.size()) {
+            for (int k = 0; k < 64; ++k) {
+                hipEvent_t ev;
+                if (hipEventCreate(&ev) != hipSuccess) { on = false; return; }
+                e->ev_pool.push_back(ev);
+            }
+        }
+        a = e->ev_pool[e->ev_next++];
+        b = e->ev_pool[e->ev_next++];
+        (void)hipEventRecord(a, e->stream);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(b, e->stream);
+        e->pending.push_back({id, a, b});
+    }
+};
+
+void prof_collect(ellp_engine *e) {
+    for (auto &p : e->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            e->kernel_ms[p.id] += ms;
+            e->kernel_calls[p.id] += 1;
+        }
+    }
+    e->pending.clear();
+    e->ev_next = 0;
+}
+
+// ---- launches -----------------------------------------------------------------------------
+template <int MODE>
+void launch_price(ellp_engine *e) {
+    PriceArgs a{};
+    a.A_N = e->A_N;
+    a.u = (MODE == 0) ? e->u : e->rho;
+    a.c_N = e->c_N;
+    a.Nb = e->Nb;
+    a.N_index = e->N_index;
+    a.dd = e->dd;
+    a.r = e->r;
+    a.key = e->key;
+    a.blockkey = e->blockkey;
+    a.blockpos = e->blockpos;
+    a.st = e->st;
+    a.ld = e->ld;
+    a.nN = e->nN;
+    a.cpb = e->cpb;
+    a.eps = e->eps;
+    dim3 g(e->nblocks), b(256);
+    switch (e->priceT) {
+    case 1: hipLaunchKernelGGL((k_price<1, MODE>), g, b, 0, e->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_price<2, MODE>), g, b, 0, e->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_price<4, MODE>), g, b, 0, e->stream, a); break;
+    case 8: hipLaunchKernelGGL((k_price<8, MODE>), g, b, 0, e->stream, a); break;
+    default: hipLaunchKernelGGL((k_price<16, MODE>), g, b, 0, e->stream, a); break;
+    }
+}
+
+void launch_ftran(ellp_engine *e, int mode) {
+    FtranArgs a{e->W, e->A_N, e->A_B, e->d, e->st, e->m, e->ld, mode};
+    hipLaunchKernelGGL(k_ftran, dim3(e->ftran_blocks), dim3(256), 0, e->stream, a);
+}
+
+void launch_update(ellp_engine *e, int update_u) {
+    UpdateArgs a{e->W, e->d, e->rho, e->u, e->st, e->m, e->ld, e->upd_rows, update_u};
+    hipLaunchKernelGGL(k_update, dim3(e->upd_blocks), dim3(256), 0, e->stream, a);
+}
+
+void launch_btran(ellp_engine *e) {
+    BtranArgs a{e->W, e->c_B, e->upart, e->u, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
+    const int64_t half = e->ld >> 1;
+    dim3 g((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles);
+    hipLaunchKernelGGL(k_btran_part, g, dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_btran_reduce, dim3((unsigned)((e->ld + 255) / 256)), dim3(256), 0, e->stream, a);
+}
+
+void launch_refactor(ellp_engine *e) {
+    Prof p(e, ELLP_K_REFACTOR);
+    RefArgs a{e->W, e->W2, e->d, e->rho, e->used, e->perm, e->st, e->m, e->ld, e->eps};
+    hipLaunchKernelGGL(k_ref_init, dim3(1024), dim3(256), 0, e->stream, a);
+    for (int64_t k = 0; k < e->m; ++k) {
+        launch_ftran(e, 1);
+        hipLaunchKernelGGL(k_ref_pick, dim3(1), dim3(1024), 0, e->stream, a);
+        launch_update(e, 0);
+    }
+    hipLaunchKernelGGL(k_ref_permute, dim3((unsigned)e->m), dim3(256), 0, e->stream, a);
+    (void)hipMemcpyAsync(e->W, e->W2, sizeof(double) * (size_t)(e->m * e->ld), hipMemcpyDeviceToDevice, e->stream);
+    e->refactors += 1;
+    e->since_refactor = 0;
+    e->u_valid = false;
+}
+
+void launch_primal_iteration(ellp_engine *e) {
+    const bool full_btran = (e->opts.btran_mode == 1) || !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;
+    if (full_btran) {
+        Prof p(e, ELLP_K_BTRAN);
+        launch_btran(e);
+        e->since_btran = 0;
+        e->u_valid = true;
+    }
+    {
+        Prof p(e, ELLP_K_PRICE);
+        launch_price<0>(e);
+    }
+    {
+        Prof p(e, ELLP_K_SELECT);
+        SelectArgs a{e->key, e->blockkey, e->r, e->N_index, e->Nb, e->st, e->nN, e->nblocks, e->cpb, e->eps};
+        hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, e->stream, a);
+    }
+    {
+        Prof p(e, ELLP_K_FTRAN);
+        launch_ftran(e, 0);
+    }
+    {
+        Prof p(e, ELLP_K_RATIO);
+        RatioArgs a{};
+        a.W = e->W; a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N;
+        a.x = e->x; a.d = e->d; a.rho = e->rho; a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv;
+        a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+        a.g_lam = e->g_lam; a.g_bidx = e->g_bidx; a.g_dpos = e->g_dpos;
+        a.st = e->st; a.m = e->m; a.ld = e->ld; a.use_lds = e->ratio_use_lds; a.eps = e->eps;
+        hipLaunchKernelGGL(k_ratio, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
+    }
+    {
+        Prof p(e, ELLP_K_UPDATE);
+        launch_update(e, e->opts.btran_mode == 1 ? 0 : 1);
+    }
+    e->since_btran += 1;
+    e->since_refactor += 1;
+}
+
+void launch_dual_iteration(ellp_engine *e) {
+    {
+        Prof p(e, ELLP_K_DLEAVE);
+        DLeaveArgs a{e->W, e->x, e->lb, e->ub, e->kindv, e->B_index, e->rho, e->st, e->m, e->ld, e->eps};
+        hipLaunchKernelGGL(k_dleave, dim3(1), dim3(1024), 0, e->stream, a);
+    }
+    {
+        Prof p(e, ELLP_K_DPRICE);
+        launch_price<1>(e);
+    }
+    {
+        Prof p(e, ELLP_K_DSELECT);
+        DSelectArgs a{e->blockkey, e->blockpos, e->st, e->nblocks};
+        hipLaunchKernelGGL(k_dselect, dim3(1), dim3(64), 0, e->stream, a);
+    }
+    {
+        Prof p(e, ELLP_K_FTRAN);
+        launch_ftran(e, 0);
+    }
+    {
+        Prof p(e, ELLP_K_DUPDATE);
+        DUpdateArgs a{};
+        a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+        a.alpha = e->r; a.alpha_q = e->d; a.rho = e->rho;
+        a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb; a.st = e->st;
+        a.m = e->m; a.ld = e->ld; a.nN = e->nN;
+        hipLaunchKernelGGL(k_dupdate, dim3(1), dim3(1024), 0, e->stream, a);
+    }
+    {
+        Prof p(e, ELLP_K_UPDATE);
+        launch_update(e, 0);
+    }
+    e->since_refactor += 1;
+}
+
+ellp_status status_message(const DevState &s, char *errbuf, size_t errlen) {
+    switch (s.status) {
+    case ELLP_ERR_SINGULAR: set_err(errbuf, errlen, "invalid B, A_B is not invertible"); break;
+    case ELLP_ERR_NAN: set_err(errbuf, errlen, "NaN detected"); break;
+    case ELLP_ERR_PANIC:
+        if (s.panic_code == 402) set_err(errbuf, errlen, "assertion failed: lambda >= 0.");
+        else if (s.panic_code == 229) set_err(errbuf, errlen, "pivot should have been unbounded");
+        else set_err(errbuf, errlen, "reference invariant violated (code %d)", s.panic_code);
+        break;
+    default: break;
+    }
+    return (ellp_status)s.status;
+}
+
+double host_dual_obj(int64_t m, int64_t n_c, const double *b, const uint8_t *kind, const double *lb,
+                     const double *ub, const double *y, const double *d) {
+    // standard_form.rs:52-68
+    double obj = 0.0;
+    for (int64_t i = 0; i < m; ++i) obj += b[i] * y[i];
+    for (int64_t i = 0; i < n_c; ++i) {
+        switch (kind[i]) {
+        case ELLP_BOUND_LOWER: obj += lb[i] * d[i]; break;
+        case ELLP_BOUND_UPPER: obj += ub[i] * d[i]; break;
+        case ELLP_BOUND_TWOSIDED: obj += (d[i] > 0.0) ? lb[i] * d[i] : ub[i] * d[i]; break;
+        case ELLP_BOUND_FIXED: obj += lb[i] * d[i]; break;
+        default: break;
+        }
+    }
+    return obj;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ellp_default_opts(ellp_opts *o) {
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->max_iter = 1000;  // Default::default(), primal…:21 / dual…:22
+    o->eps = 1e-10;      // util.rs:1
+    o->device = -1;
+}
+
+int ellp_hip_abi_version(void) { return ELLP_HIP_ABI_VERSION; }
+
+int ellp_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void ellp_engine_destroy(ellp_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->h_st) (void)hipHostFree(e->h_st);
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                               const double *b, const uint8_t *bound_kind, const double *lb, const double *ub,
+                               const double *x, const int64_t *B_index, int64_t n_B, const int64_t *N_index,
+                               const uint8_t *N_bound, int64_t n_N, const double *y, const double *d,
+                               const ellp_opts *opts_in, ellp_engine **out, char *errbuf, size_t errlen) {
+    if (!out) return ELLP_ERR_ARG;
+    *out = nullptr;
+    if (errbuf && errlen) errbuf[0] = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    if (kind != ELLP_ENGINE_PRIMAL && kind != ELLP_ENGINE_DUAL) {
+        set_err(errbuf, errlen, "unknown engine kind %d", kind);
+        return ELLP_ERR_ARG;
+    }
+    if (m <= 0) {
+        set_err(errbuf, errlen, "m == 0: the trivial problem is solved on the host (primal…:118-122)");
+        return ELLP_ERR_ARG;
+    }
+    if (n < 0 || n_c < n || !A || !c || !b || !bound_kind || !lb || !ub || !x || !B_index || (n_N > 0 && (!N_index || !N_bound))) {
+        set_err(errbuf, errlen, "null pointer or inconsistent sizes");
+        return ELLP_ERR_ARG;
+    }
+    if (kind == ELLP_ENGINE_DUAL && (!y || !d)) {
+        set_err(errbuf, errlen, "dual engine needs y and d");
+        return ELLP_ERR_ARG;
+    }
+    if (n_B != m) {  // primal…:124-130
+        set_err(errbuf, errlen, "invalid B, has %lld elements but %lld expected", (long long)n_B, (long long)m);
+        return ELLP_ERR_BAD_DIMS;
+    }
+    if (n < m) {
+        set_err(errbuf, errlen, "cols < rows");
+        return ELLP_ERR_PANIC;
+    }
+    if (n_N != n - m) {  // primal…:132-140
+        set_err(errbuf, errlen, "invalid N, has %lld elements but %lld expected", (long long)n_N, (long long)(n - m));
+        return ELLP_ERR_BAD_DIMS;
+    }
+    if (n_c >= (int64_t)1 << 31) {
+        set_err(errbuf, errlen, "n_c too large");
+        return ELLP_ERR_ARG;
+    }
+    for (int64_t i = 0; i < m; ++i)
+        if (B_index[i] < 0 || B_index[i] >= n) {
+            set_err(errbuf, errlen, "B_index[%lld] out of range", (long long)i);
+            return ELLP_ERR_ARG;
+        }
+    for (int64_t j = 0; j < n_N; ++j)
+        if (N_index[j] < 0 || N_index[j] >= n || N_bound[j] > 2) {
+            set_err(errbuf, errlen, "N_index/N_bound[%lld] out of range", (long long)j);
+            return ELLP_ERR_ARG;
+        }
+    for (int64_t i = 0; i < n_c; ++i)
+        if (bound_kind[i] > 4) {
+            set_err(errbuf, errlen, "bound_kind[%lld] out of range", (long long)i);
+            return ELLP_ERR_ARG;
+        }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err(errbuf, errlen, "no HIP device available (this library has no CPU path)");
+        return ELLP_ERR_DEVICE;
+    }
+    ellp_engine *e = new ellp_engine();
+    ellp_opts defaults;
+    ellp_default_opts(&defaults);
+    e->opts = opts_in ? *opts_in : defaults;
+    e->eps = e->opts.eps > 0.0 ? e->opts.eps : 1e-10;
+    e->kind = kind;
+    e->m = m;
+    e->n = n;
+    e->n_c = n_c;
+    e->nN = n_N;
+    e->ld = round_up(m, 16);
+    int dev = e->opts.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    e->device = dev;
+
+#define ECHK(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            set_err(errbuf, errlen, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__,   \
+                    __LINE__, #expr);                                                                \
+            ellp_engine_destroy(e);                                                                  \
+            return ELLP_ERR_DEVICE;                                                                  \
+        }                                                                                            \
+    } while (0)
+
+    ECHK(hipSetDevice(dev));
+    ECHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    const int64_t ld = e->ld;
+    const int64_t nNa = n_N > 0 ? n_N : 1;
+    // geometry
+    {
+        int64_t cpb = (n_N + 1023) / 1024;
+        if (cpb < 1) cpb = 1;
+        if (cpb > 64) cpb = 64;
+        e->cpb = (int)cpb;
+        e->nblocks = (int)((nNa + cpb - 1) / cpb);
+        const int64_t need = ((ld >> 1) + 255) / 256;
+        e->priceT = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+        if (need > 16) {
+            set_err(errbuf, errlen, "m = %lld exceeds this build's pricing tile (m <= 8192)", (long long)m);
+            ellp_engine_destroy(e);
+            return ELLP_ERR_ARG;
+        }
+        e->upd_rows = m >= 4096 ? 4 : (m >= 1024 ? 2 : 1);
+        e->upd_blocks = (int)((m + e->upd_rows - 1) / e->upd_rows);
+        int64_t fw = m < 2048 ? m : 2048;
+        e->ftran_blocks = (int)((fw + 3) / 4);
+        e->btran_rows = (int)((m + 63) / 64);
+        if (e->btran_rows < 8) e->btran_rows = 8;
+        e->btran_tiles = (int)((m + e->btran_rows - 1) / e->btran_rows);
+        const int nchunks = (int)((m + 63) >> 6);
+        size_t lds = sizeof(double) * (size_t)nchunks + (size_t)m * (8 + 4 + 1) + 16;
+        if (lds <= 60 * 1024) {
+            e->ratio_use_lds = 1;
+            e->ratio_lds = lds;
+        } else {
+            e->ratio_use_lds = 0;
+            e->ratio_lds = sizeof(double) * (size_t)nchunks + 16;
+        }
+        e->refactor_period = e->opts.refactor_period > 0 ? e->opts.refactor_period : 0;
+    }
+
+    ECHK(dmalloc(e, &e->A_B, (size_t)(ld * m)));
+    ECHK(dmalloc(e, &e->A_N, (size_t)(ld * nNa)));
+    ECHK(dmalloc(e, &e->W, (size_t)(m * ld)));
+    ECHK(dmalloc(e, &e->W2, (size_t)(m * ld)));
+    ECHK(dmalloc(e, &e->c_B, (size_t)m));
+    ECHK(dmalloc(e, &e->c_N, (size_t)nNa));
+    ECHK(dmalloc(e, &e->u, (size_t)ld));
+    ECHK(dmalloc(e, &e->r, (size_t)nNa));
+    ECHK(dmalloc(e, &e->key, (size_t)nNa));
+    ECHK(dmalloc(e, &e->blockkey, (size_t)e->nblocks));
+    ECHK(dmalloc(e, &e->blockpos, (size_t)e->nblocks));
+    ECHK(dmalloc(e, &e->x, (size_t)n_c));
+    ECHK(dmalloc(e, &e->lb, (size_t)n_c));
+    ECHK(dmalloc(e, &e->ub, (size_t)n_c));
+    ECHK(dmalloc(e, &e->kindv, (size_t)n_c));
+    ECHK(dmalloc(e, &e->d, (size_t)ld));
+    ECHK(dmalloc(e, &e->rho, (size_t)ld));
+    ECHK(dmalloc(e, &e->upart, (size_t)(e->btran_tiles * ld)));
+    ECHK(dmalloc(e, &e->B_index, (size_t)m));
+    ECHK(dmalloc(e, &e->N_index, (size_t)nNa));
+    ECHK(dmalloc(e, &e->Nb, (size_t)nNa));
+    ECHK(dmalloc(e, &e->perm, (size_t)m));
+    ECHK(dmalloc(e, &e->used, (size_t)m));
+    ECHK(dmalloc(e, &e->g_lam, (size_t)m));
+    ECHK(dmalloc(e, &e->g_bidx, (size_t)m));
+    ECHK(dmalloc(e, &e->g_dpos, (size_t)m));
+    ECHK(dmalloc(e, &e->resid, (size_t)m));
+    ECHK(dmalloc(e, &e->st, 1));
+    ECHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_st), sizeof(DevState), hipHostMallocDefault));
+    if (kind == ELLP_ENGINE_DUAL) {
+        ECHK(dmalloc(e, &e->y, (size_t)ld));
+        ECHK(dmalloc(e, &e->dd, (size_t)n_c));
+    }
+    ECHK(hipMemsetAsync(e->u, 0, sizeof(double) * (size_t)ld, e->stream));
+    ECHK(hipMemsetAsync(e->d, 0, sizeof(double) * (size_t)ld, e->stream));
+    ECHK(hipMemsetAsync(e->rho, 0, sizeof(double) * (size_t)ld, e->stream));
+
+    // upload (A goes through a temporary full copy, then columns are gathered on the device)
+    {
+        double *A_full = nullptr, *c_full = nullptr;
+        ECHK(hipMalloc(reinterpret_cast<void **>(&A_full), sizeof(double) * (size_t)(m * n > 0 ? m * n : 1)));
+        hipError_t rc = hipMalloc(reinterpret_cast<void **>(&c_full), sizeof(double) * (size_t)n_c);
+        if (rc != hipSuccess) {
+            (void)hipFree(A_full);
+            ECHK(rc);
+        }
+        auto fail = [&](hipError_t err) {
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipFree(A_full);
+            (void)hipFree(c_full);
+            return err;
+        };
+#define UCHK(expr)                              \
+    do {                                        \
+        hipError_t _u = (expr);                 \
+        if (_u != hipSuccess) { ECHK(fail(_u)); } \
+    } while (0)
+        UCHK(hipMemcpyAsync(A_full, A, sizeof(double) * (size_t)(m * n), hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(c_full, c, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(e->B_index, B_index, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, e->stream));
+        if (n_N > 0) {
+            UCHK(hipMemcpyAsync(e->N_index, N_index, sizeof(int64_t) * (size_t)n_N, hipMemcpyHostToDevice, e->stream));
+            UCHK(hipMemcpyAsync(e->Nb, N_bound, (size_t)n_N, hipMemcpyHostToDevice, e->stream));
+        }
+        UCHK(hipMemcpyAsync(e->x, x, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(e->lb, lb, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(e->ub, ub, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(e->kindv, bound_kind, (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)m), dim3(256), 0, e->stream, A_full, m, e->B_index, e->A_B, ld);
+        hipLaunchKernelGGL(k_gather_vec, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, c_full,
+                           e->B_index, e->c_B, m);
+        if (n_N > 0) {
+            hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)n_N), dim3(256), 0, e->stream, A_full, m, e->N_index,
+                               e->A_N, ld);
+            hipLaunchKernelGGL(k_gather_vec, dim3((unsigned)((n_N + 255) / 256)), dim3(256), 0, e->stream, c_full,
+                               e->N_index, e->c_N, n_N);
+        }
+        UCHK(hipGetLastError());
+        DevState init;
+        memset(&init, 0, sizeof(init));
+        init.status = ST_RUNNING;
+        init.r = -1;
+        if (kind == ELLP_ENGINE_DUAL) {
+            UCHK(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)ld, e->stream));
+            UCHK(hipMemcpyAsync(e->y, y, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, e->stream));
+            UCHK(hipMemcpyAsync(e->dd, d, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+            init.obj = host_dual_obj(m, n_c, b, bound_kind, lb, ub, y, d);  // dual…:184
+        }
+        *e->h_st = init;
+        UCHK(hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+        UCHK(hipStreamSynchronize(e->stream));
+        (void)hipFree(A_full);
+        (void)hipFree(c_full);
+#undef UCHK
+    }
+    if (e->ratio_lds > 48 * 1024) {
+        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)e->ratio_lds));
+    }
+    // dual: initial dual feasibility assertion (dual…:139-151) — host side, data is in hand
+    if (kind == ELLP_ENGINE_DUAL) {
+        for (int64_t j = 0; j < n_N; ++j) {
+            const double di = d[N_index[j]];
+            bool infeasible;
+            if (N_bound[j] == ELLP_NB_LOWER) infeasible = di < -e->eps;
+            else if (N_bound[j] == ELLP_NB_UPPER) infeasible = di > e->eps;
+            else infeasible = std::fabs(di) > e->eps;
+            if (infeasible) {
+                set_err(errbuf, errlen, "initial point of dual phase 2 is dual infeasible");
+                ellp_engine_destroy(e);
+                return ELLP_ERR_PANIC;
+            }
+        }
+    }
+    // initial B^-1
+    launch_refactor(e);
+    ECHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    ECHK(hipStreamSynchronize(e->stream));
+    ECHK(hipGetLastError());
+    prof_collect(e);
+    if (e->h_st->status != ST_RUNNING) {
+        ellp_status s = status_message(*e->h_st, errbuf, errlen);
+        ellp_engine_destroy(e);
+        return s;
+    }
+#undef ECHK
+    e->t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *out = e;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
+    if (!e) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    launch_refactor(e);
+    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen) {
+    if (!e) return ELLP_ERR_ARG;
+    if (errbuf && errlen) errbuf[0] = 0;
+    HIPCHK(hipSetDevice(e->device));
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : (e->m <= 256 ? 64 : 16);
+    int64_t period = e->refactor_period;
+    if (period <= 0) period = 100;  // default; see DESIGN.md §numerics
+    ellp_status result = ELLP_MAXITER;
+    if (e->nN == 0) {
+        result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
+    } else {
+        uint64_t remaining = max_iters;
+        // a previous slice may already have terminated
+        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->h_st->status != ST_RUNNING) {
+            result = status_message(*e->h_st, errbuf, errlen);
+            remaining = 0;
+        }
+        while (remaining > 0) {
+            const uint64_t batch = remaining < poll ? remaining : poll;
+            for (uint64_t it = 0; it < batch; ++it) {
+                if (e->since_refactor >= (uint64_t)period) launch_refactor(e);
+                if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
+                else launch_dual_iteration(e);
+            }
+            HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipGetLastError());
+            prof_collect(e);
+            remaining -= batch;
+            if (e->h_st->status != ST_RUNNING) {
+                result = status_message(*e->h_st, errbuf, errlen);
+                break;
+            }
+        }
+    }
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->iters = e->h_st->iters;
+        stats->pivots = e->h_st->pivots;
+        stats->bound_flips = e->h_st->flips;
+        stats->refactors = e->refactors;
+        stats->obj = e->h_st->obj;
+        stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats->t_setup_s = e->t_setup;
+        for (int k = 0; k < ELLP_K_COUNT; ++k) {
+            stats->kernel_ms[k] = e->kernel_ms[k];
+            stats->kernel_calls[k] = e->kernel_calls[k];
+        }
+    }
+    return result;
+}
+
+ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, int64_t *N_index, uint8_t *N_bound,
+                                   double *y, double *d, char *errbuf, size_t errlen) {
+    if (!e) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    if (x) HIPCHK(hipMemcpyAsync(x, e->x, sizeof(double) * (size_t)e->n_c, hipMemcpyDeviceToHost, e->stream));
+    if (B_index) HIPCHK(hipMemcpyAsync(B_index, e->B_index, sizeof(int64_t) * (size_t)e->m, hipMemcpyDeviceToHost, e->stream));
+    if (N_index && e->nN) HIPCHK(hipMemcpyAsync(N_index, e->N_index, sizeof(int64_t) * (size_t)e->nN, hipMemcpyDeviceToHost, e->stream));
+    if (N_bound && e->nN) HIPCHK(hipMemcpyAsync(N_bound, e->Nb, (size_t)e->nN, hipMemcpyDeviceToHost, e->stream));
+    if (e->kind == ELLP_ENGINE_DUAL) {
+        if (y) HIPCHK(hipMemcpyAsync(y, e->y, sizeof(double) * (size_t)e->m, hipMemcpyDeviceToHost, e->stream));
+        if (d) HIPCHK(hipMemcpyAsync(d, e->dd, sizeof(double) * (size_t)e->n_c, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return ELLP_OPTIMAL;
+}
+
+int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
+    if (!e || !dst) return ELLP_ERR_ARG;
+    if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    const double *src = nullptr;
+    int64_t count = 0;
+    switch (what) {
+    case ELLP_TAP_U: src = e->u; count = e->m; break;
+    case ELLP_TAP_R: src = e->r; count = e->nN; break;
+    case ELLP_TAP_ALPHA: src = e->r; count = e->nN; break;
+    case ELLP_TAP_D: src = e->d; count = e->m; break;
+    case ELLP_TAP_RHO: src = e->rho; count = e->m; break;
+    case ELLP_TAP_KEY: src = e->key; count = e->nN; break;
+    case ELLP_TAP_BINV: {
+        // row-major m x m without the padding
+        count = e->m * e->m;
+        if (count > cap) return ELLP_ERR_ARG;
+        if (hipMemcpy2DAsync(dst, sizeof(double) * (size_t)e->m, e->W, sizeof(double) * (size_t)e->ld,
+                             sizeof(double) * (size_t)e->m, (size_t)e->m, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+            return ELLP_ERR_DEVICE;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return ELLP_ERR_DEVICE;
+        return count;
+    }
+    default: return ELLP_ERR_ARG;
+    }
+    if (count > cap) count = cap;
+    if (count > 0) {
+        if (hipMemcpyAsync(dst, src, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+            return ELLP_ERR_DEVICE;
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return ELLP_ERR_DEVICE;
+    }
+    return count;
+}
+
+double ellp_engine_inverse_residual(ellp_engine *e) {
+    if (!e) return NAN;
+    if (hipSetDevice(e->device) != hipSuccess) return NAN;
+    hipLaunchKernelGGL(k_inv_residual, dim3((unsigned)e->m), dim3(256), 0, e->stream, e->W, e->A_B, e->m, e->ld,
+                       e->resid);
+    std::vector<double> h((size_t)e->m);
+    if (hipMemcpyAsync(h.data(), e->resid, sizeof(double) * (size_t)e->m, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+        return NAN;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return NAN;
+    double w = 0.0;
+    for (double v : h) w = (v > w || v != v) ? v : w;
+    return w;
+}
+
+static ellp_status solve_once(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                              const double *b, const uint8_t *bound_kind, const double *lb, const double *ub,
+                              double *x, int64_t *B_index, int64_t n_B, int64_t *N_index, uint8_t *N_bound,
+                              int64_t n_N, double *y, double *d, const ellp_opts *opts, ellp_stats *stats,
+                              char *errbuf, size_t errlen) {
+    ellp_engine *e = nullptr;
+    ellp_status s = ellp_engine_create(kind, m, n, n_c, A, c, b, bound_kind, lb, ub, x, B_index, n_B, N_index,
+                                       N_bound, n_N, y, d, opts, &e, errbuf, errlen);
+    if (s != ELLP_OPTIMAL) return s;
+    const uint64_t max_iter = opts ? opts->max_iter : 1000;
+    s = ellp_engine_run(e, max_iter, stats, errbuf, errlen);
+    if (s != ELLP_ERR_DEVICE) {
+        ellp_status rs = ellp_engine_read_point(e, x, B_index, N_index, N_bound, y, d, errbuf, errlen);
+        if (rs != ELLP_OPTIMAL) s = rs;
+    }
+    ellp_engine_destroy(e);
+    return s;
+}
+
+ellp_status ellp_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                                           const double *b, const uint8_t *bound_kind, const double *lb,
+                                           const double *ub, double *x, int64_t *B_index, int64_t n_B,
+                                           int64_t *N_index, uint8_t *N_bound, int64_t n_N, const ellp_opts *opts,
+                                           ellp_stats *stats, char *errbuf, size_t errlen) {
+    return solve_once(ELLP_ENGINE_PRIMAL, m, n, n_c, A, c, b, bound_kind, lb, ub, x, B_index, n_B, N_index, N_bound,
+                      n_N, nullptr, nullptr, opts, stats, errbuf, errlen);
+}
+
+ellp_status ellp_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                                         const double *b, const uint8_t *bound_kind, const double *lb,
+                                         const double *ub, double *x, int64_t *B_index, int64_t n_B,
+                                         int64_t *N_index, uint8_t *N_bound, int64_t n_N, double *y, double *d,
+                                         const ellp_opts *opts, ellp_stats *stats, char *errbuf, size_t errlen) {
+    return solve_once(ELLP_ENGINE_DUAL, m, n, n_c, A, c, b, bound_kind, lb, ub, x, B_index, n_B, N_index, N_bound,
+                      n_N, y, d, opts, stats, errbuf, errlen);
+}
+
+}  // extern "C"

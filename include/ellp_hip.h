@@ -1,0 +1,181 @@
+/*
+ * ellp_hip.h — C ABI of the MI355X-native revised-simplex pivot engine.
+ *
+ * Drop-in boundary for kehlert/ellp 0.2.0's hot path.  The reference has no FFI; the seam
+ * this ABI replaces is the generic method
+ *
+ *   PrimalSimplexSolver::solve_with_initial   src/solvers/primal/primal_simplex_solver.rs:95
+ *   DualSimplexSolver::solve_with_initial     src/solvers/dual/dual_simplex_solver.rs:110
+ *
+ * i.e. everything between `prob.unpack()` and the returned SolutionStatus: the per-iteration
+ * BTRAN, pricing, entering selection, FTRAN, ratio test, point update and basis swap
+ * (primal…:160-235 + pivot() :238-435; dual…:188-334).  Problem / StandardForm / phase
+ * construction / the m == 0 trivial solver stay on the host (INTEGRATION.md shows the Rust
+ * binding a maintainer would add).
+ *
+ * Conventions (mirroring what solve_with_initial has in hand, standard_form.rs:21-34):
+ *   - A is m x n, column-major, leading dimension m (nalgebra DMatrix storage), read-only.
+ *   - c, x, bound_kind/lb/ub have length n_c >= n (n_c > n only in primal phase 1 with free
+ *     variables, primal_problem.rs:141,223,250-253).  b has length m.
+ *   - Bound (problem.rs:191-197) is flattened to kind + lb + ub:
+ *       0 Free, 1 Lower(lb), 2 Upper(ub), 3 TwoSided(lb, ub), 4 Fixed(lb)
+ *   - Point{x, N, B} (standard_form.rs:21-25) is flattened to x, B_index[n_B],
+ *     N_index[n_N], N_bound[n_N] (0 Lower, 1 Upper, 2 Free; standard_form.rs:206-210) and is
+ *     updated IN PLACE, so the warm-start contract (phase 1 -> phase 2) survives.
+ *   - No unwinding across the boundary: Err(EllPError) and panics of the reference come back
+ *     as negative status codes with a message in errbuf.
+ *   - Re-entrant: no global mutable state; every call/engine owns its HIP stream.
+ *   - There is NO CPU fallback: if no HIP device is usable the call returns ELLP_ERR_DEVICE.
+ */
+#ifndef ELLP_HIP_H
+#define ELLP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELLP_HIP_ABI_VERSION 1
+
+/* SolutionStatus (src/solver.rs:28-33) + error codes */
+typedef enum ellp_status {
+    ELLP_OPTIMAL = 0,
+    ELLP_INFEASIBLE = 1,
+    ELLP_UNBOUNDED = 2,
+    ELLP_MAXITER = 3,
+    ELLP_ERR_BAD_DIMS = -1, /* Err("invalid B/N, has .. elements but .. expected") primal…:124-140 */
+    ELLP_ERR_SINGULAR = -2, /* Err("invalid B, A_B is not invertible")              primal…:175-179 */
+    ELLP_ERR_NAN = -3,      /* NaN met in pricing / ratio keys                      primal…:282    */
+    ELLP_ERR_DEVICE = -4,   /* HIP runtime error / no device / extension missing                   */
+    ELLP_ERR_ARG = -5,      /* NULL pointer, index out of range, m == 0 (host handles that case)   */
+    ELLP_ERR_PANIC = -6     /* an assert!/panic!/unwrap() of the reference would have fired        */
+} ellp_status;
+
+enum { ELLP_BOUND_FREE = 0, ELLP_BOUND_LOWER = 1, ELLP_BOUND_UPPER = 2, ELLP_BOUND_TWOSIDED = 3,
+       ELLP_BOUND_FIXED = 4 };
+enum { ELLP_NB_LOWER = 0, ELLP_NB_UPPER = 1, ELLP_NB_FREE = 2 };
+
+#define ELLP_MAX_ITER_NONE UINT64_MAX /* PrimalSimplexSolver::new(None), primal…:26-30 */
+
+typedef struct ellp_opts {
+    uint64_t max_iter;       /* self.max_iter (primal…:16, dual…:17); default 1000 (:21) */
+    double eps;              /* EPS, src/util.rs:1; <= 0 selects 1e-10 */
+    int32_t device;          /* HIP device ordinal; < 0 = current device */
+    int32_t refactor_period; /* iterations between refactorisations of B^-1; <= 0 = default */
+    int32_t btran_mode;      /* 0 default (incremental u, periodic refresh); 1 = u = B^-T c_B every iteration */
+    int32_t poll_interval;   /* iterations enqueued between host polls of the status word; <= 0 = default */
+    int32_t profile;         /* != 0: bracket every launch with HIP events (ellp_stats.kernel_ms) */
+    int32_t use_graph;       /* != 0: replay the per-iteration launch sequence from a hipGraph */
+    int32_t reserved[4];
+} ellp_opts;
+
+/* kernel ids for ellp_stats.kernel_ms / kernel_calls */
+enum {
+    ELLP_K_PRICE = 0,   /* r = c_N - A_N^T u (+ keys)          primal…:189, :253-270 */
+    ELLP_K_SELECT = 1,  /* entering fold                        primal…:271-287       */
+    ELLP_K_FTRAN = 2,   /* d = +-B^-1 a_q                       primal…:295-300, dual…:294 */
+    ELLP_K_RATIO = 3,   /* ratio test + x update + swap         primal…:305-417, :205-232 */
+    ELLP_K_UPDATE = 4,  /* rank-1 (eta) update of B^-1          (replaces primal…:173 / dual…:241) */
+    ELLP_K_BTRAN = 5,   /* u = B^-T c_B                         primal…:184-187 */
+    ELLP_K_REFACTOR = 6,/* B^-1 from A_B (all launches of one refactorisation) */
+    ELLP_K_DLEAVE = 7,  /* dual leaving scan + rho               dual…:200-253 */
+    ELLP_K_DPRICE = 8,  /* alpha = A_N^T rho (+ ratios)          dual…:255-278 */
+    ELLP_K_DSELECT = 9, /* dual ratio argmin                     dual…:279-289 */
+    ELLP_K_DUPDATE = 10,/* d, y, x updates + swap                dual…:296-333 */
+    ELLP_K_COUNT = 12
+};
+
+typedef struct ellp_stats {
+    uint64_t iters;       /* loop bodies entered (the reference's `iter` bookkeeping) */
+    uint64_t pivots;      /* basis changes */
+    uint64_t bound_flips; /* entering variable moved bound-to-bound (primal…:223-231) */
+    uint64_t refactors;
+    double obj;           /* c.x (primal) / dual objective (dual) at return */
+    double t_loop_s;      /* wall time of the device loop */
+    double t_setup_s;     /* upload + initial factorisation */
+    double kernel_ms[ELLP_K_COUNT];      /* profile != 0 only: summed HIP-event time */
+    uint64_t kernel_calls[ELLP_K_COUNT]; /* profile != 0 only */
+} ellp_stats;
+
+/* Fills *o with the defaults that reproduce reference behaviour (max_iter 1000, eps 1e-10). */
+void ellp_default_opts(ellp_opts *o);
+
+/* Number of usable HIP devices (0 if none / runtime unavailable). Never throws. */
+int ellp_hip_device_count(void);
+int ellp_hip_abi_version(void);
+
+/*
+ * PrimalSimplexSolver::solve_with_initial (primal_simplex_solver.rs:95-236).
+ * Synchronous: uploads, runs the device loop, writes x / B_index / N_index / N_bound back.
+ */
+ellp_status ellp_primal_solve_with_initial(
+    int64_t m, int64_t n, int64_t n_c,
+    const double *A, const double *c, const double *b,
+    const uint8_t *bound_kind, const double *lb, const double *ub,
+    double *x,
+    int64_t *B_index, int64_t n_B,
+    int64_t *N_index, uint8_t *N_bound, int64_t n_N,
+    const ellp_opts *opts, ellp_stats *stats, char *errbuf, size_t errbuf_len);
+
+/*
+ * DualSimplexSolver::solve_with_initial (dual_simplex_solver.rs:110-335).
+ * y (m) and d (n_c) are the DualFeasiblePoint's vectors (dual_problem.rs:12-16), in/out.
+ */
+ellp_status ellp_dual_solve_with_initial(
+    int64_t m, int64_t n, int64_t n_c,
+    const double *A, const double *c, const double *b,
+    const uint8_t *bound_kind, const double *lb, const double *ub,
+    double *x,
+    int64_t *B_index, int64_t n_B,
+    int64_t *N_index, uint8_t *N_bound, int64_t n_N,
+    double *y, double *d,
+    const ellp_opts *opts, ellp_stats *stats, char *errbuf, size_t errbuf_len);
+
+/*
+ * Resident form of the same path: the tableau stays in HBM between calls, so a caller
+ * (bench.py, a phase-1 -> phase-2 hand-off, a windowed parity test) can run the loop in
+ * slices without re-uploading.  create = unpack + gather (primal…:99-155); run = the loop for
+ * at most `max_iters` further iterations (returns ELLP_MAXITER when the slice is used up,
+ * exactly as the loop does when iter > max_iter); read = copy the point back.
+ */
+typedef struct ellp_engine ellp_engine;
+enum { ELLP_ENGINE_PRIMAL = 0, ELLP_ENGINE_DUAL = 1 };
+
+ellp_status ellp_engine_create(
+    int kind,
+    int64_t m, int64_t n, int64_t n_c,
+    const double *A, const double *c, const double *b,
+    const uint8_t *bound_kind, const double *lb, const double *ub,
+    const double *x,
+    const int64_t *B_index, int64_t n_B,
+    const int64_t *N_index, const uint8_t *N_bound, int64_t n_N,
+    const double *y, const double *d, /* dual only, else NULL */
+    const ellp_opts *opts, ellp_engine **out, char *errbuf, size_t errbuf_len);
+
+ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats,
+                            char *errbuf, size_t errbuf_len);
+
+ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index,
+                                   int64_t *N_index, uint8_t *N_bound, double *y, double *d,
+                                   char *errbuf, size_t errbuf_len);
+
+/* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
+ * the number of doubles written (<= cap) or a negative ellp_status. */
+enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,
+       ELLP_TAP_ALPHA = 5, ELLP_TAP_RHO = 6 };
+int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
+
+/* Forces a refactorisation of B^-1 now (used by tests and by the drift monitor). */
+ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errbuf_len);
+
+/* max_ij |(B^-1 A_B - I)_ij| computed on device (drift monitor; tests). */
+double ellp_engine_inverse_residual(ellp_engine *e);
+
+void ellp_engine_destroy(ellp_engine *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

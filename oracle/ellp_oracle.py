@@ -225,6 +225,21 @@ class PhaseHandle:
     def obj(self):
         return lib().eo_phase_obj(self.ptr)
 
+    def store_point(self, view):
+        """Write x/B/N/Nb (/y/d) of a Phase view back into the C struct (same sizes)."""
+        s = self.ptr.contents
+        assert view.nB == s.nB and view.n_c == s.n_c
+        C.memmove(s.x, view.x.ctypes.data, 8 * s.n_c)
+        C.memmove(s.B, view.B.ctypes.data, 8 * s.nB)
+        nN = view.nN
+        C.memmove(s.N, view.N.ctypes.data, 8 * nN)
+        C.memmove(s.Nb, view.Nb.ctypes.data, nN)
+        self.ptr.contents.nN = nN
+        if s.y and view.y is not None and s.m:
+            C.memmove(s.y, view.y.ctypes.data, 8 * s.m)
+        if s.d and view.d is not None:
+            C.memmove(s.d, view.d.ctypes.data, 8 * s.n_c)
+
     def dual_obj(self):
         return lib().eo_phase_dual_obj(self.ptr)
 

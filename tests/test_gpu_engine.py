@@ -1,0 +1,172 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on identical inputs.
+
+Inputs are the flat StandardForm + Point arrays at the solve_with_initial seam
+(primal_simplex_solver.rs:95, dual_simplex_solver.rs:110).  Bar: same SolutionStatus, same
+basis, objective and point within 1e-9 (f64; the reference's own tests use 1e-8,
+tests/problems/mod.rs:6)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, known_answers, read_mps
+from oracle import ellp_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+KA = known_answers()
+TOL = 1e-9
+
+
+def _engine():
+    from ellp_amd import _engine as E
+    return E
+
+
+def flat_from_view(v):
+    E = _engine()
+    return E.FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B,
+                         v.N[:v.nN], v.Nb[:v.nN], v.y, v.d)
+
+
+def run_both(view, which, max_iter=None, **optkw):
+    """Runs oracle and GPU on copies of the same phase view. Returns (oracle_view, st_o, it_o, fp, st_g, stats)."""
+    E = _engine()
+    ov = view.copy()
+    if which == "primal":
+        st_o, it_o, err_o = eo.primal_solve_with_initial(ov, eo.MAX_ITER_NONE if max_iter is None else max_iter)
+    else:
+        st_o, it_o, err_o = eo.dual_solve_with_initial(ov, eo.MAX_ITER_NONE if max_iter is None else max_iter)
+    fp = flat_from_view(view)
+    opts = E.default_opts(max_iter=max_iter, **optkw)
+    if which == "primal":
+        st_g, stats, err_g = E.primal_solve_with_initial(fp, opts)
+    else:
+        st_g, stats, err_g = E.dual_solve_with_initial(fp, opts)
+    return ov, st_o, it_o, fp, st_g, stats, err_g
+
+
+def assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis=True):
+    assert st_g == st_o, f"status gpu={st_g} oracle={st_o}"
+    if st_o in (eo.OPTIMAL, eo.MAXITER):
+        scale = 1.0 + np.max(np.abs(ov.x)) if ov.x.size else 1.0
+        np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=TOL * scale)
+        assert abs(fp.obj() - ov.obj()) <= TOL * (1.0 + abs(ov.obj()))
+        if exact_basis:
+            assert stats.iters == it_o, f"iterations gpu={stats.iters} oracle={it_o}"
+            np.testing.assert_array_equal(fp.B, ov.B)
+            np.testing.assert_array_equal(fp.N[:fp.nN], ov.N[:ov.nN])
+            np.testing.assert_array_equal(fp.Nb[:fp.nN], ov.Nb[:ov.nN])
+        else:
+            assert sorted(fp.B.tolist()) == sorted(ov.B.tolist())
+
+
+def primal_two_phase(fx, exact_basis=True, **optkw):
+    """Mirrors PrimalSimplexSolver::solve (primal…:32-93) with the GPU loop checked against the
+    oracle loop phase by phase on identical inputs."""
+    prob = eo.Problem.from_fixture(fx)
+    p1, err = eo.primal_phase1(prob)
+    if p1 is None:
+        return "infeasible-by-setup"
+    v1 = p1.view()
+    if v1.m == 0:
+        return "trivial"
+    ov, st_o, it_o, fp, st_g, stats, err_g = run_both(v1, "primal", 1000, **optkw)
+    assert st_g >= 0, err_g
+    assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis)
+    if st_o != eo.OPTIMAL or not (ov.obj() < eo.lib().eo_phase_obj(p1.ptr) * 0 + 1e-10):
+        return "phase1-only"
+    p1.store_point(ov)
+    p2 = eo.primal_phase2(p1)
+    v2 = p2.view()
+    ov2, st_o2, it_o2, fp2, st_g2, stats2, err_g2 = run_both(v2, "primal", 1000, **optkw)
+    assert st_g2 >= 0, err_g2
+    assert_same_point(ov2, fp2, st_o2, st_g2, it_o2, stats2, exact_basis)
+    return eo.STATUS_NAME[st_o2], fp2
+
+
+@pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
+def test_primal_known_answers(fx):
+    out = primal_two_phase(fx, refactor_period=1 << 30)
+    if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj"):
+        status, fp2 = out
+        assert status == "optimal"
+        assert abs(fp2.obj() - fx["obj"]) < 1e-8
+        if fx["check"] == "optimal":
+            np.testing.assert_allclose(fp2.x[:len(fx["x"])], fx["x"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("fx", KA["netlib"], ids=[p["name"] for p in KA["netlib"]])
+def test_primal_netlib(fx):
+    prob_fx = read_mps(os.path.join(GOLDEN, fx["file"]))
+    out = primal_two_phase(prob_fx)
+    assert isinstance(out, tuple)
+    status, fp2 = out
+    assert status == "optimal"
+    assert abs(fp2.obj() / fx["obj"] - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("m,n", [(20, 50), (50, 120), (100, 250)])
+def test_primal_synthetic_full_solve(m, n):
+    """SURVEY §8d family, full solve (both phases), pivot-for-pivot against the oracle."""
+    A, b, c = eo.synth_dense_lp(20260301, m, n)
+    fx = {"vars": [[float(c[j]), ["Lower", 0.0, 0.0]] for j in range(n)],
+          "constraints": [[[[j, float(A[i, j])] for j in range(n)], "Lte", float(b[i])] for i in range(m)]}
+    prob = eo.Problem.from_fixture(fx)
+    p1, err = eo.primal_phase1(prob)
+    v1 = p1.view()
+    ov, st_o, it_o, fp, st_g, stats, err_g = run_both(v1, "primal", None)
+    assert st_g >= 0, err_g
+    assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis=True)
+    p1.store_point(ov)
+    p2 = eo.primal_phase2(p1)
+    ov2, st_o2, it_o2, fp2, st_g2, stats2, err_g2 = run_both(p2.view(), "primal", None)
+    assert st_g2 >= 0, err_g2
+    assert_same_point(ov2, fp2, st_o2, st_g2, it_o2, stats2, exact_basis=True)
+
+
+def dual_two_phase(fx, exact_basis=True, **optkw):
+    prob = eo.Problem.from_fixture(fx)
+    p1, err = eo.dual_phase1(prob)
+    if p1 is None:
+        return "infeasible-by-setup"
+    v1 = p1.view()
+    if v1.m == 0:
+        return "trivial"
+    ov, st_o, it_o, fp, st_g, stats, err_g = run_both(v1, "dual", 1000, **optkw)
+    assert st_g >= 0, err_g
+    assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis)
+    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=TOL * (1 + np.max(np.abs(ov.y))))
+    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=TOL * (1 + np.max(np.abs(ov.d))))
+    p1.store_point(ov)
+    if st_o != eo.OPTIMAL or not (p1.dual_obj() > -1e-10):
+        return "phase1-only"
+    p2, err = eo.dual_phase2(p1)
+    assert p2 is not None
+    v2 = p2.view()
+    if v2.m == 0:
+        return "trivial"
+    ov2, st_o2, it_o2, fp2, st_g2, stats2, err_g2 = run_both(v2, "dual", 1000, **optkw)
+    assert st_g2 >= 0, err_g2
+    assert_same_point(ov2, fp2, st_o2, st_g2, it_o2, stats2, exact_basis)
+    return eo.STATUS_NAME[st_o2], fp2
+
+
+@pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
+def test_dual_known_answers(fx):
+    out = dual_two_phase(fx, refactor_period=1 << 30)
+    if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj") and out[0] == "optimal":
+        status, fp2 = out
+        assert abs(fp2.obj() - fx["obj"]) < 1e-8
+        if fx["check"] == "optimal":
+            np.testing.assert_allclose(fp2.x[:len(fx["x"])], fx["x"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("fx", KA["netlib"], ids=[p["name"] for p in KA["netlib"]])
+def test_dual_netlib(fx):
+    prob_fx = read_mps(os.path.join(GOLDEN, fx["file"]))
+    out = dual_two_phase(prob_fx)
+    assert isinstance(out, tuple)
+    status, fp2 = out
+    assert status == "optimal"
+    assert abs(fp2.obj() / fx["obj"] - 1.0) < 1e-6
