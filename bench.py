@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — simplex pivots/sec + achieved HBM GB/s of the HIP pivot engine.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one iteration of the revised-simplex loop (one pass of the hot path:
+BTRAN/pricing/entering/FTRAN/ratio/eta-update) on the synthetic dense LP of BASELINE.json's
+config 3 (m=2000, n=5000, primal; SURVEY.md §8d generator), started from the reference's own
+phase-1 starting basis, tableau already resident in HBM.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured-achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--m", type=int, default=2000)
+    ap.add_argument("--n", type=int, default=5000)
+    ap.add_argument("--seed", type=int, default=20260301)
+    ap.add_argument("--solver", choices=["primal"], default="primal")
+    ap.add_argument("--cpu-pivots", type=int, default=-1, help="oracle pivots to time (-1 auto, 0 off)")
+    ap.add_argument("--profile-steps", type=int, default=200)
+    ap.add_argument("--refactor-period", type=int, default=0)
+    ap.add_argument("--btran-mode", type=int, default=0)
+    ap.add_argument("--poll", type=int, default=0)
+    ap.add_argument("--check", action="store_true", help="compare the first pivots with the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(flat, pivots):
+    """The oracle's loop (LU refactorisation every iteration, single thread — the reference's
+    algorithm) timed on this host over a bounded window from the same starting basis."""
+    from oracle import ellp_oracle as eo
+
+    class V:
+        pass
+    v = V()
+    for k in ("m", "n", "n_c", "A", "c", "b", "kind", "lb", "ub"):
+        setattr(v, k, flat[k])
+    v.x = flat["x"].copy()
+    v.B = flat["B"].copy()
+    v.N = flat["N"].copy()
+    v.Nb = flat["Nb"].copy()
+    v.nB, v.nN = len(v.B), len(v.N)
+    eo.set_dense_lu(True)  # pay nalgebra's full (2/3) m^3 per iteration, as the reference does
+    t0 = time.perf_counter()
+    st, iters, _ = eo.primal_solve_with_initial(v, pivots)
+    dt = time.perf_counter() - t0
+    eo.set_dense_lu(False)
+    return iters / dt, iters, dt, v
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+
+    m, n = args.m, args.n
+    flat = synth.primal_phase1_flat(args.seed, m, n)
+    fp = E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
+                       flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"])
+    nN = fp.nN
+    ld = (m + 15) // 16 * 16
+
+    def make_engine(profile):
+        opts = E.default_opts(max_iter=None, device=local_rank, refactor_period=args.refactor_period,
+                              btran_mode=args.btran_mode, poll_interval=args.poll, profile=profile)
+        return E.Engine(E.ENGINE_PRIMAL, fp, opts)
+
+    # ---- timed region: tableau resident, W warm-up steps, then exactly K steps
+    eng = make_engine(0)
+    st, stats, msg = eng.run(args.warmup)
+    assert st in (E.MAXITER,), f"warm-up ended the solve: {E.STATUS_NAME.get(st)} {msg}"
+    it0 = stats.iters
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    st, stats, msg = eng.run(args.steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    steps_done = stats.iters - it0
+    assert st == E.MAXITER and steps_done == args.steps, (E.STATUS_NAME.get(st), steps_done, msg)
+    refactors = stats.refactors
+    resid = eng.inverse_residual()
+    eng.close()
+
+    # ---- per-kernel durations (HIP events on the engine's stream), same start, separate run
+    prof = {}
+    if args.profile_steps > 0:
+        engp = make_engine(1)
+        engp.run(args.warmup)
+        st, ps, _ = engp.run(args.profile_steps)
+        pd = ps.as_dict()
+        for k, ms in pd["kernel_ms"].items():
+            prof[k] = {"calls": int(pd["kernel_calls"][k]), "avg_us": 1e3 * ms / max(1, pd["kernel_calls"][k])}
+        engp.close()
+
+    if rank != 0:
+        return
+    pivots_per_s = world * args.steps / dt  # N>1: every rank runs the same pivot stream
+    if world > 1:
+        pivots_per_s = args.steps / dt
+    price_bytes = 8.0 * ld * nN
+    roofline = None
+    if "price" in prof:
+        t_us = prof["price"]["avg_us"]
+        ach = price_bytes / (t_us * 1e-6) / 1e9
+        roofline = {"kernel": "k_price", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": price_bytes, "avg_us": round(t_us, 3)}
+    cpu = None
+    cpu_pivots = args.cpu_pivots
+    if cpu_pivots < 0:
+        # ~10-30 s of CPU work: one oracle pivot costs ~(2/3) m^3 flops of unblocked LU
+        est = (2.0 / 3.0) * m ** 3 / 2.5e9 + 1e-3
+        cpu_pivots = int(max(3, min(2000, 15.0 / est)))
+    if cpu_pivots > 0:
+        rate, iters, cdt, _ = cpu_baseline(flat, cpu_pivots)
+        cpu = {"value": round(rate, 4), "unit": "pivots/s", "cores": 1, "kind": "port",
+               "sample": f"first {iters} pivots of the same LP from the same starting basis, {cdt:.1f} s, "
+                         "oracle/ellp_oracle.c (LU refactor every iteration, single thread)"}
+    alg_bytes_per_pivot = 8.0 * ld * nN + 32.0 * m * ld
+    out = {
+        "metric": "simplex pivots/sec (dense LP, primal, tableau resident in HBM)",
+        "value": round(pivots_per_s, 2), "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 6), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"random dense LP m={m} n={n} (seed {args.seed}), primal simplex phase 1, "
+                               f"std-form {m}x{fp.n} with |N|={nN}", "refactors_in_window": int(refactors),
+                   "inverse_residual_after": resid},
+        "achieved_GBps_algorithmic": round(alg_bytes_per_pivot * args.steps / dt / 1e9, 1),
+        "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v["avg_us"], 3) for k, v in prof.items()},
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(pivots_per_s / cpu["value"], 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

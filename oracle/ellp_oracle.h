@@ -129,6 +129,10 @@ typedef void (*eo_trace_fn)(void *user, uint64_t iter, int64_t entering_pos,
                             int64_t leaving_pos, int64_t entering_var, int64_t leaving_var);
 void eo_set_trace(eo_trace_fn fn, void *user);
 
+/* 1: LU/solves do nalgebra's full dense work (no zero-multiplier skip) — used when the oracle
+ * is TIMED as the CPU baseline; results are identical either way. */
+void eo_set_dense_lu(int on);
+
 typedef struct eo_result {
     int status;       /* EO_OPTIMAL.. or error */
     double obj;       /* Optimal: c.x ; MaxIter: obj field of SolverResult::MaxIter */

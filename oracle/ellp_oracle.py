@@ -101,6 +101,7 @@ def lib():
     L.eo_solve.restype = C.c_int
     L.eo_solve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(_Result)]
     L.eo_result_free.argtypes = [C.POINTER(_Result)]
+    L.eo_set_dense_lu.argtypes = [C.c_int]
     L.eo_synth_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
     _lib = L
@@ -316,6 +317,11 @@ def solve(prob, solver="primal", max_iter=1000):
     out = Result(r)
     lib().eo_result_free(C.byref(r))
     return out
+
+
+def set_dense_lu(on):
+    """Timed-baseline mode: no zero-multiplier skip in LU (nalgebra does the full dense work)."""
+    lib().eo_set_dense_lu(1 if on else 0)
 
 
 def synth_dense_lp(seed, m, n):
