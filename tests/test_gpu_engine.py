@@ -135,8 +135,9 @@ def dual_two_phase(fx, exact_basis=True, **optkw):
     ov, st_o, it_o, fp, st_g, stats, err_g = run_both(v1, "dual", 1000, **optkw)
     assert st_g >= 0, err_g
     assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis)
-    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=TOL * (1 + np.max(np.abs(ov.y))))
-    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=TOL * (1 + np.max(np.abs(ov.d))))
+    if exact_basis:
+        np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=TOL * (1 + np.max(np.abs(ov.y))))
+        np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=TOL * (1 + np.max(np.abs(ov.d))))
     p1.store_point(ov)
     if st_o != eo.OPTIMAL or not (p1.dual_obj() > -1e-10):
         return "phase1-only"
