@@ -1,0 +1,201 @@
+// solvers.cpp — PrimalSimplexSolver / DualSimplexSolver drivers.
+//   solve():                primal_simplex_solver.rs:32-93, dual_simplex_solver.rs:33-108 (host)
+//   solve_with_initial():   the seam.  Checks that stay on the host are the ones the reference
+//                           does before its loop (m == 0 -> trivial solver); everything else is
+//                           one call through the C ABI into the HIP engine.  No CPU loop exists
+//                           here: if the engine cannot run, the error is raised.
+#include <cmath>
+
+#include "ellp.h"
+
+namespace ellp {
+
+namespace {
+
+struct Flat {
+    std::vector<std::uint8_t> kind;
+    std::vector<double> lb, ub;
+    std::vector<std::int64_t> B, N;
+    std::vector<std::uint8_t> Nb;
+};
+
+Flat flatten(const StandardForm &sf, const Point &pt) {
+    Flat f;
+    const size_t nc = sf.bounds.size();
+    f.kind.resize(nc);
+    f.lb.resize(nc);
+    f.ub.resize(nc);
+    for (size_t i = 0; i < nc; ++i) {
+        f.kind[i] = static_cast<std::uint8_t>(sf.bounds[i].kind);
+        f.lb[i] = sf.bounds[i].lb;
+        f.ub[i] = (sf.bounds[i].kind == Bound::Fixed) ? sf.bounds[i].lb : sf.bounds[i].ub;
+    }
+    for (const auto &b : pt.B) f.B.push_back(static_cast<std::int64_t>(b.index));
+    for (const auto &n : pt.N) {
+        f.N.push_back(static_cast<std::int64_t>(n.index));
+        f.Nb.push_back(static_cast<std::uint8_t>(n.bound));
+    }
+    return f;
+}
+
+void unflatten(const Flat &f, Point &pt) {
+    for (size_t i = 0; i < pt.B.size(); ++i) pt.B[i].index = static_cast<size_t>(f.B[i]);
+    for (size_t j = 0; j < pt.N.size(); ++j) {
+        pt.N[j].index = static_cast<size_t>(f.N[j]);
+        pt.N[j].bound = static_cast<NonbasicBound>(f.Nb[j]);
+    }
+}
+
+ellp_opts make_opts(std::uint64_t max_iter, const EngineOptions &e) {
+    ellp_opts o;
+    ellp_default_opts(&o);
+    o.max_iter = max_iter;
+    o.eps = EPS;
+    o.device = e.device;
+    o.refactor_period = e.refactor_period;
+    o.btran_mode = e.btran_mode;
+    o.poll_interval = e.poll_interval;
+    return o;
+}
+
+SolutionStatus to_status(ellp_status s, const char *err) {
+    switch (s) {
+    case ELLP_OPTIMAL: return SolutionStatus::Optimal;
+    case ELLP_INFEASIBLE: return SolutionStatus::Infeasible;
+    case ELLP_UNBOUNDED: return SolutionStatus::Unbounded;
+    case ELLP_MAXITER: return SolutionStatus::MaxIter;
+    case ELLP_ERR_BAD_DIMS:
+    case ELLP_ERR_SINGULAR: throw EllPError(err);  // Err(EllPError), primal…:124-140, :175-179
+    case ELLP_ERR_DEVICE: throw std::runtime_error(std::string("HIP engine unavailable: ") + err);
+    default: throw EllPPanic(err);
+    }
+}
+
+}  // namespace
+
+// primal_simplex_solver.rs:95-236
+SolutionStatus PrimalSimplexSolver::solve_with_initial(const StandardForm &sf, Point &pt, std::uint64_t *iters) const {
+    if (iters) *iters = 0;
+    if (sf.rows() == 0) {  // :118-122
+        if (!pt.B.empty()) throw EllPPanic("assertion failed: B.is_empty()");
+        return solve_trivial_problem(sf, pt.x, pt.N, true);
+    }
+    Flat f = flatten(sf, pt);
+    const ellp_opts o = make_opts(max_iter_, engine_);
+    ellp_stats st{};
+    char err[512] = {0};
+    const ellp_status s = ellp_primal_solve_with_initial(
+        static_cast<std::int64_t>(sf.rows()), static_cast<std::int64_t>(sf.cols()),
+        static_cast<std::int64_t>(sf.bounds.size()), sf.A.a.data(), sf.c.data(), sf.b.data(), f.kind.data(),
+        f.lb.data(), f.ub.data(), pt.x.data(), f.B.data(), static_cast<std::int64_t>(f.B.size()), f.N.data(),
+        f.Nb.data(), static_cast<std::int64_t>(f.N.size()), &o, &st, err, sizeof(err));
+    if (iters) *iters = st.iters;
+    const SolutionStatus out = to_status(s, err);
+    unflatten(f, pt);
+    return out;
+}
+
+// primal_simplex_solver.rs:32-93
+SolverResult PrimalSimplexSolver::solve(Problem prob) const {
+    SolverResult res;
+    auto p1 = PrimalPhase1::from_problem(std::move(prob));
+    if (!p1) { res.kind = SolverResult::Infeasible; return res; }
+    PrimalPhase1 phase_1 = std::move(*p1);
+    switch (solve_with_initial(phase_1.std_form, phase_1.point, &res.iters_phase1)) {
+    case SolutionStatus::Optimal: {
+        const double obj = phase_1.obj();
+        if (!(obj > -EPS)) throw EllPPanic("assertion failed: obj > -EPS");
+        if (!(obj < EPS)) { res.kind = SolverResult::Infeasible; return res; }
+        break;
+    }
+    case SolutionStatus::Infeasible: res.kind = SolverResult::Infeasible; return res;
+    case SolutionStatus::Unbounded: throw EllPPanic("primal phase 1 should never be unbounded");
+    case SolutionStatus::MaxIter:
+        res.kind = SolverResult::MaxIter;
+        res.max_iter_obj = std::numeric_limits<double>::infinity();
+        return res;
+    }
+    PrimalPhase2 phase_2 = PrimalPhase2::from_phase1(std::move(phase_1));
+    switch (solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2)) {
+    case SolutionStatus::Optimal:
+        res.kind = SolverResult::Optimal;
+        res.solution = Solution{std::move(phase_2.std_form), std::move(phase_2.point)};
+        return res;
+    case SolutionStatus::Infeasible: throw EllPPanic("primal phase 2 should never be infeasible");
+    case SolutionStatus::Unbounded: res.kind = SolverResult::Unbounded; return res;
+    case SolutionStatus::MaxIter:
+        res.kind = SolverResult::MaxIter;
+        res.max_iter_obj = phase_2.obj();
+        return res;
+    }
+    return res;
+}
+
+// dual_simplex_solver.rs:110-335
+SolutionStatus DualSimplexSolver::solve_with_initial(const StandardForm &sf, DualFeasiblePoint &dp,
+                                                     std::uint64_t *iters) const {
+    if (iters) *iters = 0;
+    Point &pt = dp.point;
+    if (sf.rows() == 0) {  // :132-136
+        if (!pt.B.empty()) throw EllPPanic("assertion failed: B.is_empty()");
+        return solve_trivial_problem(sf, pt.x, pt.N, true);
+    }
+    Flat f = flatten(sf, pt);
+    const ellp_opts o = make_opts(max_iter_, engine_);
+    ellp_stats st{};
+    char err[512] = {0};
+    const ellp_status s = ellp_dual_solve_with_initial(
+        static_cast<std::int64_t>(sf.rows()), static_cast<std::int64_t>(sf.cols()),
+        static_cast<std::int64_t>(sf.bounds.size()), sf.A.a.data(), sf.c.data(), sf.b.data(), f.kind.data(),
+        f.lb.data(), f.ub.data(), pt.x.data(), f.B.data(), static_cast<std::int64_t>(f.B.size()), f.N.data(),
+        f.Nb.data(), static_cast<std::int64_t>(f.N.size()), dp.y.data(), dp.d.data(), &o, &st, err, sizeof(err));
+    if (iters) *iters = st.iters;
+    const SolutionStatus out = to_status(s, err);
+    unflatten(f, pt);
+    return out;
+}
+
+// dual_simplex_solver.rs:33-108
+SolverResult DualSimplexSolver::solve(Problem prob) const {
+    SolverResult res;
+    Problem orig_for_fallback = prob;  // phase_1.into_orig_prob()
+    auto p1 = DualPhase1::from_problem(std::move(prob));
+    if (!p1) { res.kind = SolverResult::Infeasible; return res; }
+    DualPhase1 phase_1 = std::move(*p1);
+    switch (solve_with_initial(phase_1.std_form, phase_1.point, &res.iters_phase1)) {
+    case SolutionStatus::Optimal: {
+        const double obj = phase_1.obj();
+        if (!(obj < EPS)) throw EllPPanic("assertion failed: obj < EPS");
+        if (!(obj > -EPS)) {
+            // dual infeasible: classify with the primal solver, default max_iter (dual…:51-66)
+            SolverResult r = PrimalSimplexSolver().with_engine(engine_).solve(std::move(orig_for_fallback));
+            if (r.kind == SolverResult::Optimal)
+                throw EllPPanic("assertion failed: matches!(result, Infeasible | Unbounded | MaxIter)");
+            return r;
+        }
+        break;
+    }
+    case SolutionStatus::Infeasible: throw EllPPanic("dual phase 1 should never be infeasible");
+    case SolutionStatus::Unbounded: throw EllPPanic("dual phase 1 should never be unbounded");
+    case SolutionStatus::MaxIter:
+        res.kind = SolverResult::MaxIter;
+        res.max_iter_obj = std::numeric_limits<double>::infinity();
+        return res;
+    }
+    DualPhase2 phase_2 = DualPhase2::from_phase1(std::move(phase_1));
+    switch (solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2)) {
+    case SolutionStatus::Optimal:
+        res.kind = SolverResult::Optimal;
+        res.solution = Solution{std::move(phase_2.std_form), std::move(phase_2.point.point)};
+        return res;
+    case SolutionStatus::Infeasible: res.kind = SolverResult::Infeasible; return res;
+    case SolutionStatus::Unbounded: throw EllPPanic("dual phase 2 should never return unbounded");
+    case SolutionStatus::MaxIter:
+        res.kind = SolverResult::MaxIter;
+        res.max_iter_obj = phase_2.obj();
+        return res;
+    }
+    return res;
+}
+
+}  // namespace ellp

