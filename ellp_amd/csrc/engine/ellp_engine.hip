@@ -13,9 +13,11 @@
 //   A_N  : ld x n_N column-major  — nonbasic columns, physically swapped on a pivot exactly as
 //          the reference swaps them (primal…:211-217); pricing streams it once per iteration.
 //   A_B  : ld x m  column-major  — basic columns (only read by the refactorisation).
-//   W    : m x ld  ROW-major     — B^-1.  Row-major so that FTRAN (d_i = W[i,:].a_q) is one
-//          coalesced dot product per row, the dual's rho = row r of B^-1 is one contiguous
-//          copy, and the eta update streams whole rows.
+//   W[2] : m x ld  ROW-major     — B^-1, two buffers.  Row-major so that FTRAN (d_i = W[i,:].a_q)
+//          is one coalesced dot product per row, the dual's rho = row r of B^-1 is one
+//          contiguous row, and the eta update streams whole rows.  The eta update reads buffer
+//          `cur^1` and writes buffer `cur` (ping-pong): no block ever reads a row another block
+//          is overwriting, and the pivot row needs no staging copy.
 //   u, rho, d, x, c_B, c_N, keys : vectors.
 //
 // There is no CPU path in this file: without a HIP device every entry point returns
@@ -45,6 +47,8 @@ struct DevState {
     int32_t side;       // bound the leaving variable goes to
     int32_t nan_flag;
     int32_t panic_code; // which assert of the reference fired
+    int32_t cur;        // index of the B^-1 buffer that is current
+    int32_t swap_cols;  // the eta update also swaps A_B[:,r] <-> A_N[:,q] (not during refactorisation)
     int64_t q;          // entering position in N
     int64_t r;          // leaving position in B, -1 = none
     int64_t refk;       // refactorisation step
@@ -87,7 +91,8 @@ __device__ __forceinline__ double wave_max(double v) {
 // loads outstanding.  HBM-bound: 8*ld bytes per column, 2 flops per 8 bytes.
 struct PriceArgs {
     const double *A_N;
-    const double *u;      // primal: u ; dual: rho
+    const double *W0, *W1; // dual: rho = row st->r of the current B^-1 buffer (dual…:248-253)
+    const double *u;      // primal: u
     const double *c_N;    // primal only
     const uint8_t *Nb;
     const int64_t *N_index;
@@ -110,7 +115,8 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     if (a.st->status != ST_RUNNING) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t half = a.ld >> 1;
-    const double2 *u2 = reinterpret_cast<const double2 *>(a.u);
+    const double2 *u2 = reinterpret_cast<const double2 *>(
+        MODE == 0 ? a.u : ((a.st->cur ? a.W1 : a.W0) + a.st->r * a.ld));
     double2 ur[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -229,6 +235,9 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
 // reduction; instead ONE wave walks the pricing blocks in position order and uses ballots to
 // skip everything that cannot change the accumulator: a block whose maximum key is
 // <= acc - EPS holds no such element.  Work is O(#blocks/64 + #accumulator changes).
+// The whole 256-thread block first stages the block maxima (and, when they fit, all keys and
+// variable indices) into LDS with independent coalesced loads, so the serial walk never waits
+// on global memory.
 struct SelectArgs {
     const double *key, *blockkey, *r;
     const int64_t *N_index;
@@ -236,13 +245,42 @@ struct SelectArgs {
     DevState *st;
     int64_t nN;
     int nblocks, cpb;
+    int stage_keys;  // keys + indices fit in LDS
     double eps;
 };
 
-__global__ __launch_bounds__(64) void k_select(SelectArgs a) {
+__global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
     DevState *st = a.st;
     if (st->status != ST_RUNNING) return;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    double *s_bk = reinterpret_cast<double *>(smem);
+    double *s_key = s_bk + a.nblocks;
+    int32_t *s_idx = reinterpret_cast<int32_t *>(s_key + (a.stage_keys ? a.nN : 0));
+    for (int b = tid; b < a.nblocks; b += 1024) s_bk[b] = a.blockkey[b];
+    if (a.stage_keys) {
+        // batches of 8 independent loads per thread: one memory round trip per 8192 columns
+        for (int64_t j0 = tid; j0 < a.nN; j0 += 8 * 1024) {
+            double kk[8];
+            long long ii[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = j0 + (int64_t)u * 1024;
+                kk[u] = j < a.nN ? a.key[j] : 0.0;
+                ii[u] = j < a.nN ? a.N_index[j] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = j0 + (int64_t)u * 1024;
+                if (j < a.nN) {
+                    s_key[j] = kk[u];
+                    s_idx[j] = (int32_t)ii[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid >= WAVE) return;
     if (st->nan_flag) {
         if (lane == 0) st->status = ELLP_ERR_NAN;
         return;
@@ -251,7 +289,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
     double racc = 0.0;
     long long iacc = 0, qacc = -1;
     for (int g0 = 0; g0 < a.nblocks; g0 += WAVE) {
-        const double bm = (g0 + lane < a.nblocks) ? a.blockkey[g0 + lane] : -INFINITY;
+        const double bm = (g0 + lane < a.nblocks) ? s_bk[g0 + lane] : -INFINITY;
         int from = 0;
         for (;;) {
             const bool pred = lane >= from && bm > -INFINITY && (!have || bm > racc - a.eps);
@@ -261,8 +299,17 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
             const int64_t jb = (int64_t)(g0 + bl) * a.cpb;
             const int64_t j = jb + lane;
             const bool valid = lane < a.cpb && j < a.nN;
-            const double k = valid ? a.key[j] : -INFINITY;
-            const long long idx = valid ? a.N_index[j] : 0;
+            double k = -INFINITY;
+            long long idx = 0;
+            if (valid) {
+                if (a.stage_keys) {
+                    k = s_key[j];
+                    idx = s_idx[j];
+                } else {
+                    k = a.key[j];
+                    idx = a.N_index[j];
+                }
+            }
             int efrom = 0;
             for (;;) {
                 bool ev = lane >= efrom && k > -INFINITY;
@@ -300,7 +347,7 @@ __global__ __launch_bounds__(64) void k_select(SelectArgs a) {
 // lane, a_q re-read through L1/L2 (it is 8*ld bytes, W is 8*m*ld).  mode 0: column q of A_N,
 // sign from st->at_lower.  mode 1 (refactorisation): column st->refk of A_B, sign +.
 struct FtranArgs {
-    const double *W;
+    const double *W0, *W1;
     const double *A_N, *A_B;
     double *d;
     DevState *st;
@@ -314,6 +361,7 @@ __global__ __launch_bounds__(256) void k_ftran(FtranArgs a) {
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     const int64_t half = a.ld >> 1;
+    const double *W = a.st->cur ? a.W1 : a.W0;
     const double2 *col;
     double sgn = 1.0;
     if (a.mode == 0) {
@@ -323,14 +371,21 @@ __global__ __launch_bounds__(256) void k_ftran(FtranArgs a) {
         col = reinterpret_cast<const double2 *>(a.A_B + a.st->refk * a.ld);
     }
     for (int64_t i = wave_global; i < a.m; i += nwaves) {
-        const double2 *row = reinterpret_cast<const double2 *>(a.W + i * a.ld);
+        const double2 *row = reinterpret_cast<const double2 *>(W + i * a.ld);
         double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 4
-        for (int64_t t = lane; t < half; t += WAVE) {
-            const double2 w = row[t];
-            const double2 c = col[t];
-            acc0 = fma(w.x, c.x, acc0);
-            acc1 = fma(w.y, c.y, acc1);
+        for (int64_t t0 = lane; t0 < half; t0 += 8 * WAVE) {
+            double2 w[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t t = t0 + u * WAVE;
+                w[u] = t < half ? row[t] : make_double2(0.0, 0.0);
+                c[u] = t < half ? col[t] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc0 = fma(w[u].x, c[u].x, acc0);
+                acc1 = fma(w[u].y, c[u].y, acc1);
+            }
         }
         const double s = wave_sum(acc0 + acc1);
         if (lane == 0) a.d[i] = sgn * s;
@@ -343,11 +398,12 @@ __global__ __launch_bounds__(256) void k_ftran(FtranArgs a) {
 // Phase B (wave 0): exact emulation of the sequential fold (primal…:379-399), including the
 // quirk that `new_basic_index` is only written in the tie branch; ballots skip every chunk
 // whose minimum cannot touch the running lambda.  Phase C (all waves): x update
-// (primal…:408-417), index / column / cost swap (primal…:205-221) or bound flip (:223-231),
-// and a copy of row r of B^-1 (rho) for the eta update.
+// (primal…:408-417), index / cost swap (primal…:205-221) or bound flip (:223-231); the column
+// swap and the eta update of B^-1 are left to k_update, which this kernel arms by flipping the
+// current-buffer index.
 struct RatioArgs {
-    double *W, *A_N, *A_B, *c_B, *c_N, *x, *d, *rho;
-    const double *lb, *ub;
+    double *c_B, *c_N, *x;
+    const double *d, *lb, *ub;
     const uint8_t *kind;
     int64_t *B_index, *N_index;
     uint8_t *Nb;
@@ -355,11 +411,12 @@ struct RatioArgs {
     int32_t *g_bidx;
     uint8_t *g_dpos;
     DevState *st;
-    int64_t m, ld;
+    int64_t m;
     int use_lds;
     double eps;
 };
 
+template <int RE>
 __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_lambda;
@@ -387,42 +444,59 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
     const int64_t jq = a.N_index[q];
     const int at_lower = st->at_lower;
     const double eps = a.eps;
+    const int kq = a.kind[jq];
+    const double lbq = a.lb[jq], ubq = a.ub[jq];
 
-    // ---- phase A
-    for (int c = wave; c < nchunks; c += 16) {
-        const int64_t i = (int64_t)c * 64 + lane;
+    // ---- phase A: thread t owns basic rows t, t+1024, ... (RE of them), held in registers so
+    // that the two dependent gathers (B_index -> x/bounds) are one round trip each.
+    double di[RE], xi[RE];
+    int32_t bi[RE];
+#pragma unroll
+    for (int k = 0; k < RE; ++k) {
+        const int64_t i = tid + 1024 * k;
+        di[k] = i < m ? a.d[i] : 0.0;
+        bi[k] = i < m ? (int32_t)a.B_index[i] : 0;
+    }
+    double lbi[RE], ubi[RE];
+    int kd[RE];
+#pragma unroll
+    for (int k = 0; k < RE; ++k) {
+        const int64_t i = tid + 1024 * k;
+        xi[k] = i < m ? a.x[bi[k]] : 0.0;
+        kd[k] = i < m ? a.kind[bi[k]] : ELLP_BOUND_FREE;
+        lbi[k] = i < m ? a.lb[bi[k]] : 0.0;
+        ubi[k] = i < m ? a.ub[bi[k]] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < RE; ++k) {
+        const int64_t i = tid + 1024 * k;
+        const int c = wave + 16 * k;
+        if (c >= nchunks) continue;  // wave-uniform
         double li = INFINITY;
-        int32_t bi = 0;
-        bool dp = false;
-        if (i < m) {
-            const double di = a.d[i];
-            bi = (int32_t)a.B_index[i];
-            dp = di > 0.0;
-            if (!(fabs(di) < eps)) {
-                const double xi = a.x[bi];
-                const int k = a.kind[bi];
-                const double lbi = a.lb[bi], ubi = a.ub[bi];
-                if (k == ELLP_BOUND_FREE) {
-                    li = INFINITY;
-                } else if (k == ELLP_BOUND_LOWER) {
-                    if (di > 0.0) li = INFINITY;
-                    else if (xi > lbi) li = (lbi - xi) / di;
-                    else li = 0.0;
-                } else if (k == ELLP_BOUND_UPPER) {
-                    if (di > 0.0) li = (xi < ubi) ? (ubi - xi) / di : 0.0;
-                    else li = INFINITY;
-                } else if (k == ELLP_BOUND_TWOSIDED) {
-                    if (di > 0.0) li = (xi < ubi) ? (ubi - xi) / di : 0.0;
-                    else if (xi < lbi) li = (lbi - xi) / di;  // quirk Q1 (primal…:359)
-                    else li = 0.0;
-                } else {
-                    li = 0.0;  // Fixed
-                }
-                if (li != li) st->nan_flag = 1;
+        if (i < m && !(fabs(di[k]) < eps)) {
+            const double d_i = di[k], x_i = xi[k];
+            if (kd[k] == ELLP_BOUND_FREE) {
+                li = INFINITY;
+            } else if (kd[k] == ELLP_BOUND_LOWER) {
+                if (d_i > 0.0) li = INFINITY;
+                else if (x_i > lbi[k]) li = (lbi[k] - x_i) / d_i;
+                else li = 0.0;
+            } else if (kd[k] == ELLP_BOUND_UPPER) {
+                if (d_i > 0.0) li = (x_i < ubi[k]) ? (ubi[k] - x_i) / d_i : 0.0;
+                else li = INFINITY;
+            } else if (kd[k] == ELLP_BOUND_TWOSIDED) {
+                if (d_i > 0.0) li = (x_i < ubi[k]) ? (ubi[k] - x_i) / d_i : 0.0;
+                else if (x_i < lbi[k]) li = (lbi[k] - x_i) / d_i;  // quirk Q1 (primal…:359)
+                else li = 0.0;
+            } else {
+                li = 0.0;  // Fixed
             }
+            if (li != li) st->nan_flag = 1;
+        }
+        if (i < m) {
             lam[i] = li;
-            bidx[i] = bi;
-            dpos[i] = dp ? 1 : 0;
+            bidx[i] = bi[k];
+            dpos[i] = di[k] > 0.0 ? 1 : 0;
         }
         const double cm = wave_min(li);
         if (lane == 0) chunkmin[c] = cm;
@@ -432,12 +506,9 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
     // ---- phase B
     if (wave == 0) {
         double lambda;
-        {
-            const int k = a.kind[jq];
-            if (k == ELLP_BOUND_TWOSIDED) lambda = a.ub[jq] - a.lb[jq];
-            else if (k == ELLP_BOUND_FIXED) lambda = 0.0;
-            else lambda = INFINITY;
-        }
+        if (kq == ELLP_BOUND_TWOSIDED) lambda = ubq - lbq;  // primal…:305-311
+        else if (kq == ELLP_BOUND_FIXED) lambda = 0.0;
+        else lambda = INFINITY;
         long long nb = -1;
         int side = ELLP_NB_LOWER;
         bool have_nbi = false;
@@ -452,12 +523,12 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
                 const int cl = __ffsll((long long)mask) - 1;
                 const int64_t i = (int64_t)(g0 + cl) * 64 + lane;
                 const double li = (i < m) ? lam[i] : INFINITY;
-                const int32_t bi = (i < m) ? bidx[i] : 0;
+                const int32_t b_i = (i < m) ? bidx[i] : 0;
                 const int dp = (i < m) ? dpos[i] : 0;
                 int efrom = 0;
                 for (;;) {
                     const bool strict = li < lambda - eps;
-                    const bool tie = !strict && fabs(li - lambda) < eps && (!have_nbi || bi < nbi);
+                    const bool tie = !strict && fabs(li - lambda) < eps && (!have_nbi || b_i < nbi);
                     const bool ev = lane >= efrom && (strict || tie);
                     const unsigned long long em = __ballot(ev);
                     if (!em) break;
@@ -468,7 +539,7 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
                     side = __shfl(dp, l) ? ELLP_NB_UPPER : ELLP_NB_LOWER;
                     if (was_tie) {
                         have_nbi = true;
-                        nbi = __shfl(bi, l);
+                        nbi = __shfl(b_i, l);
                     }
                     efrom = l + 1;
                 }
@@ -504,32 +575,25 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
         }
         return;
     }
-    if (lambda > 0.0) {
-        for (int64_t i = tid; i < m; i += 1024) {
-            const int64_t bi = a.B_index[i];
-            a.x[bi] = a.x[bi] + lambda * a.d[i];
+    if (lambda > 0.0) {  // primal…:408-417
+#pragma unroll
+        for (int k = 0; k < RE; ++k) {
+            const int64_t i = tid + 1024 * k;
+            if (i < m) a.x[bi[k]] = xi[k] + lambda * di[k];
         }
         if (tid == 0) {
             if (at_lower) a.x[jq] = a.x[jq] + lambda;
             else a.x[jq] = a.x[jq] - lambda;
         }
     }
-    __syncthreads();
-    if (nbp >= 0) {
-        const int64_t r = nbp;
-        for (int64_t j = tid; j < a.ld; j += 1024) {
-            a.rho[j] = a.W[r * a.ld + j];
-            const double t = a.A_N[q * a.ld + j];
-            a.A_N[q * a.ld + j] = a.A_B[r * a.ld + j];
-            a.A_B[r * a.ld + j] = t;
-        }
-        if (tid == 0) {
+    if (tid == 0) {
+        if (nbp >= 0) {
+            const int64_t r = nbp;
             const double tc = a.c_N[q];
             a.c_N[q] = a.c_B[r];
             a.c_B[r] = tc;
-            const int64_t ti = a.B_index[r];
-            a.B_index[r] = a.N_index[q];
-            a.N_index[q] = ti;
+            a.N_index[q] = a.B_index[r];
+            a.B_index[r] = jq;
             a.Nb[q] = (uint8_t)s_side;
             const double dr = a.d[r];
             const double alpha_r = at_lower ? -dr : dr;
@@ -539,12 +603,12 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
             st->d_r = dr;
             st->alpha_r = alpha_r;
             st->ucoef = st->rq / alpha_r;
+            st->swap_cols = 1;
+            st->cur ^= 1;  // k_update reads buffer cur^1 and writes buffer cur
             st->do_update = 1;
             st->pivots += 1;
             st->iters += 1;
-        }
-    } else {
-        if (tid == 0) {
+        } else {
             const int nbq = a.Nb[q];
             st->r = -1;
             st->lambda = lambda;
@@ -562,13 +626,14 @@ __global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
 }
 
 // ------------------------------------------------------------------ eta update of B^-1
-// W[i,:] -= (d_i/d_r) * rho   (i != r),   W[r,:] = rho / alpha_r.   16*m*ld bytes (read+write),
-// rows with d_i == 0 are untouched.  The last block also carries the O(m) BTRAN update
-// u += (r_q/alpha_r) * rho when the engine runs in incremental-u mode.
+// dst[i,:] = src[i,:] - (d_i/d_r) * src[r,:]   (i != r),   dst[r,:] = src[r,:] / alpha_r,
+// src = buffer cur^1, dst = buffer cur.  16*m*ld bytes (read + write).  The last block also
+// swaps the columns A_B[:,r] <-> A_N[:,q] (primal…:211-217, dual…:325-331) and carries the O(m)
+// BTRAN update u += (r_q/alpha_r) * rho when the engine runs in incremental-u mode.
 struct UpdateArgs {
-    double *W;
-    const double *d, *rho;
-    double *u;
+    double *W0, *W1;
+    const double *d;
+    double *u, *A_N, *A_B;
     DevState *st;
     int64_t m, ld;
     int rows_per_block;
@@ -582,38 +647,64 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a) {
     const int64_t half = a.ld >> 1;
     const int64_t r = st->r;
     const double d_r = st->d_r, alpha_r = st->alpha_r;
-    const double2 *rho2 = reinterpret_cast<const double2 *>(a.rho);
-    for (int rr = 0; rr < a.rows_per_block; ++rr) {
-        const int64_t i = (int64_t)blockIdx.x * a.rows_per_block + rr;
-        if (i >= a.m) break;
-        double2 *row = reinterpret_cast<double2 *>(a.W + i * a.ld);
-        if (i == r) {
-            for (int64_t t = tid; t < half; t += 256) {
-                const double2 p = rho2[t];
-                row[t] = make_double2(p.x / alpha_r, p.y / alpha_r);
-            }
-        } else {
-            const double di = a.d[i];
-            if (di == 0.0) continue;
-            const double f = -(di / d_r);
-            for (int64_t t = tid; t < half; t += 256) {
-                const double2 p = rho2[t];
-                double2 w = row[t];
-                w.x = fma(f, p.x, w.x);
-                w.y = fma(f, p.y, w.y);
-                row[t] = w;
+    const double *src = st->cur ? a.W0 : a.W1;
+    double *dst = st->cur ? a.W1 : a.W0;
+    const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
+    // UPD_ROWS rows per pass: every thread keeps UPD_ROWS independent 16-byte loads in flight
+    // and re-uses its rho chunk for all of them.
+    constexpr int UPD_ROWS = 4;
+    for (int rr = 0; rr < a.rows_per_block; rr += UPD_ROWS) {
+        const int64_t i0 = (int64_t)blockIdx.x * a.rows_per_block + rr;
+        if (i0 >= a.m) break;
+        double f[UPD_ROWS];
+        int64_t ii[UPD_ROWS];
+#pragma unroll
+        for (int k = 0; k < UPD_ROWS; ++k) {
+            const int64_t i = i0 + k;
+            const bool ok = i < a.m && rr + k < a.rows_per_block;
+            ii[k] = ok ? i : -1;
+            f[k] = (ok && i != r) ? -(a.d[i] / d_r) : 0.0;
+        }
+        for (int64_t t = tid; t < half; t += 256) {
+            const double2 p = rho2[t];
+            double2 w[UPD_ROWS];
+#pragma unroll
+            for (int k = 0; k < UPD_ROWS; ++k)
+                if (ii[k] >= 0) w[k] = reinterpret_cast<const double2 *>(src + ii[k] * a.ld)[t];
+#pragma unroll
+            for (int k = 0; k < UPD_ROWS; ++k) {
+                if (ii[k] < 0) continue;
+                double2 o;
+                if (ii[k] == r) {
+                    o = make_double2(p.x / alpha_r, p.y / alpha_r);
+                } else {
+                    o.x = fma(f[k], p.x, w[k].x);
+                    o.y = fma(f[k], p.y, w[k].y);
+                }
+                reinterpret_cast<double2 *>(dst + ii[k] * a.ld)[t] = o;
             }
         }
     }
-    if (a.update_u && blockIdx.x == gridDim.x - 1) {
-        const double cf = st->ucoef;
-        double2 *u2 = reinterpret_cast<double2 *>(a.u);
-        for (int64_t t = tid; t < half; t += 256) {
-            const double2 p = rho2[t];
-            double2 w = u2[t];
-            w.x = fma(cf, p.x, w.x);
-            w.y = fma(cf, p.y, w.y);
-            u2[t] = w;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (a.update_u) {
+            const double cf = st->ucoef;
+            double2 *u2 = reinterpret_cast<double2 *>(a.u);
+            for (int64_t t = tid; t < half; t += 256) {
+                const double2 p = rho2[t];
+                double2 w = u2[t];
+                w.x = fma(cf, p.x, w.x);
+                w.y = fma(cf, p.y, w.y);
+                u2[t] = w;
+            }
+        }
+        if (st->swap_cols) {
+            double2 *cn = reinterpret_cast<double2 *>(a.A_N + st->q * a.ld);
+            double2 *cb = reinterpret_cast<double2 *>(a.A_B + r * a.ld);
+            for (int64_t t = tid; t < half; t += 256) {
+                const double2 x = cn[t];
+                cn[t] = cb[t];
+                cb[t] = x;
+            }
         }
     }
 }
@@ -623,7 +714,7 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a) {
 // then a fixed-order reduction — deterministic, no atomics.  Rows with c_B[i] == 0 are skipped
 // (phase 1: only artificial basics carry cost).
 struct BtranArgs {
-    const double *W, *c_B;
+    const double *W0, *W1, *c_B;
     double *upart, *u;
     DevState *st;
     int64_t m, ld;
@@ -638,7 +729,7 @@ __global__ __launch_bounds__(256) void k_btran_part(BtranArgs a) {
     const int64_t i1 = (i0 + a.rows_per_tile < a.m) ? i0 + a.rows_per_tile : a.m;
     double2 acc = make_double2(0.0, 0.0);
     if (j2 < half) {
-        const double2 *W2 = reinterpret_cast<const double2 *>(a.W);
+        const double2 *W2 = reinterpret_cast<const double2 *>(a.st->cur ? a.W1 : a.W0);
         for (int64_t i = i0; i < i1; ++i) {
             const double ci = a.c_B[i];
             if (ci != 0.0) {
@@ -655,7 +746,15 @@ __global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= a.ld) return;
     double s = 0.0;
-    for (int t = 0; t < a.ntiles; ++t) s += a.upart[(int64_t)t * a.ld + j];
+    int t = 0;
+    for (; t + 8 <= a.ntiles; t += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a.upart[(int64_t)(t + k) * a.ld + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    for (; t < a.ntiles; ++t) s += a.upart[(int64_t)t * a.ld + j];
     a.u[j] = s;
 }
 
@@ -667,7 +766,7 @@ __global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
 // (any |U_ii| < EPS, primal…:175-179) is checked on them.  Afterwards rows are permuted so that
 // row k belongs to basic position k.
 struct RefArgs {
-    double *W, *W2, *d, *rho;
+    double *W0, *W1, *d;
     int32_t *used;
     int64_t *perm;
     DevState *st;
@@ -677,10 +776,11 @@ struct RefArgs {
 
 __global__ __launch_bounds__(256) void k_ref_init(RefArgs a) {
     if (a.st->status != ST_RUNNING) return;
+    double *W = a.st->cur ? a.W1 : a.W0;
     const int64_t total = a.m * a.ld;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int64_t i = t / a.ld, j = t - i * a.ld;
-        a.W[t] = (i == j) ? 1.0 : 0.0;
+        W[t] = (i == j) ? 1.0 : 0.0;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.m; i += (int64_t)gridDim.x * 256) a.used[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.st->refk = 0;
@@ -724,44 +824,47 @@ __global__ __launch_bounds__(1024) void k_ref_pick(RefArgs a) {
                 bi = s_i[w];
             }
         }
-        s_i[0] = bi;
-        s_v[0] = bv;
-    }
-    __syncthreads();
-    const long long p = s_i[0];
-    const double pv = s_v[0];
-    if (p < 0 || pv < a.eps || pv != pv) {
-        if (tid == 0) st->status = ELLP_ERR_SINGULAR;
-        return;
-    }
-    for (int64_t j = tid; j < a.ld; j += 1024) a.rho[j] = a.W[p * a.ld + j];
-    if (tid == 0) {
-        a.used[p] = 1;
-        a.perm[st->refk] = p;
-        st->r = p;
-        st->d_r = a.d[p];
-        st->alpha_r = a.d[p];
-        st->do_update = 1;
-        st->refk += 1;
+        const long long p = bi;
+        if (p < 0 || bv < a.eps || bv != bv) {
+            st->status = ELLP_ERR_SINGULAR;
+        } else {
+            a.used[p] = 1;
+            a.perm[st->refk] = p;
+            st->r = p;
+            st->d_r = a.d[p];
+            st->alpha_r = a.d[p];
+            st->swap_cols = 0;
+            st->cur ^= 1;
+            st->do_update = 1;
+            st->refk += 1;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_ref_permute(RefArgs a) {
+    // reads buffer cur, writes buffer cur^1; k_ref_finish then flips cur
     if (a.st->status != ST_RUNNING) return;
+    const double *src = a.st->cur ? a.W1 : a.W0;
+    double *dstb = a.st->cur ? a.W0 : a.W1;
     const int64_t k = blockIdx.x;
     const int64_t p = a.perm[k];
-    const double2 *src = reinterpret_cast<const double2 *>(a.W + p * a.ld);
-    double2 *dst = reinterpret_cast<double2 *>(a.W2 + k * a.ld);
-    for (int64_t t = threadIdx.x; t < (a.ld >> 1); t += 256) dst[t] = src[t];
-    if (k == 0 && threadIdx.x == 0) a.st->do_update = 0;
+    const double2 *s = reinterpret_cast<const double2 *>(src + p * a.ld);
+    double2 *dst = reinterpret_cast<double2 *>(dstb + k * a.ld);
+    for (int64_t t = threadIdx.x; t < (a.ld >> 1); t += 256) dst[t] = s[t];
+}
+__global__ void k_ref_finish(RefArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    a.st->cur ^= 1;
+    a.st->do_update = 0;
 }
 
 // max |W A_B - I| (drift monitor, test/diagnostic only — m^3 work)
-__global__ __launch_bounds__(256) void k_inv_residual(const double *W, const double *A_B, int64_t m, int64_t ld,
-                                                      double *out) {
+__global__ __launch_bounds__(256) void k_inv_residual(const double *W0, const double *W1, const DevState *st,
+                                                      const double *A_B, int64_t m, int64_t ld, double *out) {
     __shared__ double s_m[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = blockIdx.x;
+    const double *W = st->cur ? W1 : W0;
     const double2 *row = reinterpret_cast<const double2 *>(W + i * ld);
     double worst = 0.0;
     for (int64_t k = wave; k < m; k += 4) {
@@ -783,15 +886,14 @@ __global__ __launch_bounds__(256) void k_inv_residual(const double *W, const dou
 
 // ------------------------------------------------------------------ dual kernels
 // leaving row: FIRST basic position (in B order) whose variable violates a bound by more than
-// EPS (dual…:200-236) — a min-position reduction, exact as a tree.  Also copies rho = row r of
-// B^-1 (dual…:248-253 obtains the same row by two triangular solves).
+// EPS (dual…:200-236) — a min-position reduction, exact as a tree.  rho = row r of B^-1
+// (dual…:248-253 obtains it by two triangular solves) is simply row r of the current buffer.
 struct DLeaveArgs {
-    const double *W, *x, *lb, *ub;
+    const double *x, *lb, *ub;
     const uint8_t *kind;
     const int64_t *B_index;
-    double *rho;
     DevState *st;
-    int64_t m, ld;
+    int64_t m;
     double eps;
 };
 
@@ -833,26 +935,18 @@ __global__ __launch_bounds__(1024) void k_dleave(DLeaveArgs a) {
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 16; ++w) best = s_i[w] < best ? s_i[w] : best;
-        s_i[0] = best;
-    }
-    __syncthreads();
-    const long long r = s_i[0];
-    if (r == INT64_MAX) {
-        if (tid == 0) {
+        if (best == INT64_MAX) {
             st->iters += 1;
             st->status = ELLP_OPTIMAL;  // dual…:243-246
+        } else {
+            double delta = 0.0;
+            int side = 0;
+            dual_violation(a, best, &delta, &side);
+            st->r = best;
+            st->delta = delta;
+            st->side = side;
+            st->do_update = 0;
         }
-        return;
-    }
-    for (int64_t j = tid; j < a.ld; j += 1024) a.rho[j] = a.W[r * a.ld + j];
-    if (tid == 0) {
-        double delta = 0.0;
-        int side = 0;
-        dual_violation(a, r, &delta, &side);
-        st->r = r;
-        st->delta = delta;
-        st->side = side;
-        st->do_update = 0;
     }
 }
 
@@ -903,10 +997,11 @@ __global__ __launch_bounds__(64) void k_dselect(DSelectArgs a) {
     }
 }
 
-// d, y, x updates and the basis swap (dual…:296-333)
+// d, y, x updates and the index swap (dual…:296-333); arms the eta update.
 struct DUpdateArgs {
-    double *A_N, *A_B, *c_B, *c_N, *x, *y, *dd;
-    const double *alpha, *alpha_q, *rho;
+    const double *W0, *W1;
+    double *c_B, *c_N, *x, *y, *dd;
+    const double *alpha, *alpha_q;
     int64_t *B_index, *N_index;
     uint8_t *Nb;
     DevState *st;
@@ -922,22 +1017,18 @@ __global__ __launch_bounds__(1024) void k_dupdate(DUpdateArgs a) {
     const int64_t entering_var = a.N_index[q];
     const double aqr = a.alpha_q[r];
     const double theta_p = delta / aqr;
+    const double *rho = (st->cur ? a.W1 : a.W0) + r * a.ld;
     for (int64_t j = tid; j < a.nN; j += 1024) {
         if (j == q) continue;
         const int64_t v = a.N_index[j];
         a.dd[v] = a.dd[v] - theta_d * a.alpha[j];
     }
     for (int64_t i = tid; i < a.m; i += 1024) {
-        a.y[i] = a.y[i] + theta_d * a.rho[i];
+        a.y[i] = a.y[i] + theta_d * rho[i];
         const int64_t bi = a.B_index[i];
         a.x[bi] = a.x[bi] - theta_p * a.alpha_q[i];
     }
     __syncthreads();
-    for (int64_t j = tid; j < a.ld; j += 1024) {
-        const double t = a.A_N[q * a.ld + j];
-        a.A_N[q * a.ld + j] = a.A_B[r * a.ld + j];
-        a.A_B[r * a.ld + j] = t;
-    }
     if (tid == 0) {
         a.dd[leaving_var] = -theta_d;
         a.dd[entering_var] = 0.0;
@@ -952,6 +1043,8 @@ __global__ __launch_bounds__(1024) void k_dupdate(DUpdateArgs a) {
         a.c_B[r] = tc;
         st->d_r = aqr;
         st->alpha_r = aqr;
+        st->swap_cols = 1;
+        st->cur ^= 1;
         st->do_update = 1;
         st->pivots += 1;
         st->iters += 1;
@@ -986,7 +1079,7 @@ struct ellp_engine {
     // device memory
     double *A_B = nullptr, *A_N = nullptr, *W = nullptr, *W2 = nullptr;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *r = nullptr, *key = nullptr;
-    double *blockkey = nullptr, *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr, *rho = nullptr;
+    double *blockkey = nullptr, *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *g_lam = nullptr, *resid = nullptr;
     int64_t *blockpos = nullptr, *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
     uint8_t *kindv = nullptr, *Nb = nullptr, *g_dpos = nullptr;
@@ -1000,6 +1093,8 @@ struct ellp_engine {
     int btran_tiles = 1, btran_rows = 1;
     int ratio_use_lds = 1;
     size_t ratio_lds = 0;
+    int select_stage = 0;
+    size_t select_lds = 0;
     // loop bookkeeping
     uint64_t since_refactor = 0, since_btran = 0;
     int refactor_period = 0;
@@ -1093,7 +1188,9 @@ template <int MODE>
 void launch_price(ellp_engine *e) {
     PriceArgs a{};
     a.A_N = e->A_N;
-    a.u = (MODE == 0) ? e->u : e->rho;
+    a.W0 = e->W;
+    a.W1 = e->W2;
+    a.u = e->u;
     a.c_N = e->c_N;
     a.Nb = e->Nb;
     a.N_index = e->N_index;
@@ -1118,17 +1215,17 @@ void launch_price(ellp_engine *e) {
 }
 
 void launch_ftran(ellp_engine *e, int mode) {
-    FtranArgs a{e->W, e->A_N, e->A_B, e->d, e->st, e->m, e->ld, mode};
+    FtranArgs a{e->W, e->W2, e->A_N, e->A_B, e->d, e->st, e->m, e->ld, mode};
     hipLaunchKernelGGL(k_ftran, dim3(e->ftran_blocks), dim3(256), 0, e->stream, a);
 }
 
 void launch_update(ellp_engine *e, int update_u) {
-    UpdateArgs a{e->W, e->d, e->rho, e->u, e->st, e->m, e->ld, e->upd_rows, update_u};
+    UpdateArgs a{e->W, e->W2, e->d, e->u, e->A_N, e->A_B, e->st, e->m, e->ld, e->upd_rows, update_u};
     hipLaunchKernelGGL(k_update, dim3(e->upd_blocks), dim3(256), 0, e->stream, a);
 }
 
 void launch_btran(ellp_engine *e) {
-    BtranArgs a{e->W, e->c_B, e->upart, e->u, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
+    BtranArgs a{e->W, e->W2, e->c_B, e->upart, e->u, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
     const int64_t half = e->ld >> 1;
     dim3 g((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles);
     hipLaunchKernelGGL(k_btran_part, g, dim3(256), 0, e->stream, a);
@@ -1137,7 +1234,7 @@ void launch_btran(ellp_engine *e) {
 
 void launch_refactor(ellp_engine *e) {
     Prof p(e, ELLP_K_REFACTOR);
-    RefArgs a{e->W, e->W2, e->d, e->rho, e->used, e->perm, e->st, e->m, e->ld, e->eps};
+    RefArgs a{e->W, e->W2, e->d, e->used, e->perm, e->st, e->m, e->ld, e->eps};
     hipLaunchKernelGGL(k_ref_init, dim3(1024), dim3(256), 0, e->stream, a);
     for (int64_t k = 0; k < e->m; ++k) {
         launch_ftran(e, 1);
@@ -1145,7 +1242,7 @@ void launch_refactor(ellp_engine *e) {
         launch_update(e, 0);
     }
     hipLaunchKernelGGL(k_ref_permute, dim3((unsigned)e->m), dim3(256), 0, e->stream, a);
-    (void)hipMemcpyAsync(e->W, e->W2, sizeof(double) * (size_t)(e->m * e->ld), hipMemcpyDeviceToDevice, e->stream);
+    hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, e->stream, a);
     e->refactors += 1;
     e->since_refactor = 0;
     e->u_valid = false;
@@ -1165,8 +1262,9 @@ void launch_primal_iteration(ellp_engine *e) {
     }
     {
         Prof p(e, ELLP_K_SELECT);
-        SelectArgs a{e->key, e->blockkey, e->r, e->N_index, e->Nb, e->st, e->nN, e->nblocks, e->cpb, e->eps};
-        hipLaunchKernelGGL(k_select, dim3(1), dim3(64), 0, e->stream, a);
+        SelectArgs a{e->key, e->blockkey, e->r, e->N_index, e->Nb, e->st, e->nN, e->nblocks, e->cpb,
+                     e->select_stage, e->eps};
+        hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), e->select_lds, e->stream, a);
     }
     {
         Prof p(e, ELLP_K_FTRAN);
@@ -1175,12 +1273,14 @@ void launch_primal_iteration(ellp_engine *e) {
     {
         Prof p(e, ELLP_K_RATIO);
         RatioArgs a{};
-        a.W = e->W; a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N;
-        a.x = e->x; a.d = e->d; a.rho = e->rho; a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv;
+        a.c_B = e->c_B; a.c_N = e->c_N;
+        a.x = e->x; a.d = e->d; a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv;
         a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
         a.g_lam = e->g_lam; a.g_bidx = e->g_bidx; a.g_dpos = e->g_dpos;
-        a.st = e->st; a.m = e->m; a.ld = e->ld; a.use_lds = e->ratio_use_lds; a.eps = e->eps;
-        hipLaunchKernelGGL(k_ratio, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
+        a.st = e->st; a.m = e->m; a.use_lds = e->ratio_use_lds; a.eps = e->eps;
+        if (e->m <= 2048) hipLaunchKernelGGL(k_ratio<2>, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
+        else if (e->m <= 4096) hipLaunchKernelGGL(k_ratio<4>, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
+        else hipLaunchKernelGGL(k_ratio<8>, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
     }
     {
         Prof p(e, ELLP_K_UPDATE);
@@ -1193,7 +1293,7 @@ void launch_primal_iteration(ellp_engine *e) {
 void launch_dual_iteration(ellp_engine *e) {
     {
         Prof p(e, ELLP_K_DLEAVE);
-        DLeaveArgs a{e->W, e->x, e->lb, e->ub, e->kindv, e->B_index, e->rho, e->st, e->m, e->ld, e->eps};
+        DLeaveArgs a{e->x, e->lb, e->ub, e->kindv, e->B_index, e->st, e->m, e->eps};
         hipLaunchKernelGGL(k_dleave, dim3(1), dim3(1024), 0, e->stream, a);
     }
     {
@@ -1212,8 +1312,8 @@ void launch_dual_iteration(ellp_engine *e) {
     {
         Prof p(e, ELLP_K_DUPDATE);
         DUpdateArgs a{};
-        a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
-        a.alpha = e->r; a.alpha_q = e->d; a.rho = e->rho;
+        a.W0 = e->W; a.W1 = e->W2; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+        a.alpha = e->r; a.alpha_q = e->d;
         a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb; a.st = e->st;
         a.m = e->m; a.ld = e->ld; a.nN = e->nN;
         hipLaunchKernelGGL(k_dupdate, dim3(1), dim3(1024), 0, e->stream, a);
@@ -1395,7 +1495,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
             ellp_engine_destroy(e);
             return ELLP_ERR_ARG;
         }
-        e->upd_rows = m >= 4096 ? 4 : (m >= 1024 ? 2 : 1);
+        e->upd_rows = m >= 1024 ? 4 : (m >= 256 ? 2 : 1);
         e->upd_blocks = (int)((m + e->upd_rows - 1) / e->upd_rows);
         int64_t fw = m < 2048 ? m : 2048;
         e->ftran_blocks = (int)((fw + 3) / 4);
@@ -1404,7 +1504,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         e->btran_tiles = (int)((m + e->btran_rows - 1) / e->btran_rows);
         const int nchunks = (int)((m + 63) >> 6);
         size_t lds = sizeof(double) * (size_t)nchunks + (size_t)m * (8 + 4 + 1) + 16;
-        if (lds <= 60 * 1024) {
+        if (lds <= 140 * 1024) {
             e->ratio_use_lds = 1;
             e->ratio_lds = lds;
         } else {
@@ -1412,6 +1512,15 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
             e->ratio_lds = sizeof(double) * (size_t)nchunks + 16;
         }
         e->refactor_period = e->opts.refactor_period > 0 ? e->opts.refactor_period : 0;
+        // entering selection: stage keys + indices in LDS when they fit (<= 140 KiB)
+        const size_t stage = sizeof(double) * (size_t)e->nblocks + (size_t)nNa * 12 + 16;
+        if (stage <= 140 * 1024) {
+            e->select_stage = 1;
+            e->select_lds = stage;
+        } else {
+            e->select_stage = 0;
+            e->select_lds = sizeof(double) * (size_t)e->nblocks + 16;
+        }
     }
 
     ECHK(dmalloc(e, &e->A_B, (size_t)(ld * m)));
@@ -1430,7 +1539,6 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->ub, (size_t)n_c));
     ECHK(dmalloc(e, &e->kindv, (size_t)n_c));
     ECHK(dmalloc(e, &e->d, (size_t)ld));
-    ECHK(dmalloc(e, &e->rho, (size_t)ld));
     ECHK(dmalloc(e, &e->upart, (size_t)(e->btran_tiles * ld)));
     ECHK(dmalloc(e, &e->B_index, (size_t)m));
     ECHK(dmalloc(e, &e->N_index, (size_t)nNa));
@@ -1449,7 +1557,6 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     }
     ECHK(hipMemsetAsync(e->u, 0, sizeof(double) * (size_t)ld, e->stream));
     ECHK(hipMemsetAsync(e->d, 0, sizeof(double) * (size_t)ld, e->stream));
-    ECHK(hipMemsetAsync(e->rho, 0, sizeof(double) * (size_t)ld, e->stream));
 
     // upload (A goes through a temporary full copy, then columns are gathered on the device)
     {
@@ -1510,8 +1617,16 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
 #undef UCHK
     }
     if (e->ratio_lds > 48 * 1024) {
-        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)e->ratio_lds));
+        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)e->ratio_lds));
+        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)e->ratio_lds));
+    }
+    if (e->select_lds > 48 * 1024) {
+        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)e->select_lds));
     }
     // dual: initial dual feasibility assertion (dual…:139-151) — host side, data is in hand
     if (kind == ELLP_ENGINE_DUAL) {
@@ -1637,13 +1752,15 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
     case ELLP_TAP_R: src = e->r; count = e->nN; break;
     case ELLP_TAP_ALPHA: src = e->r; count = e->nN; break;
     case ELLP_TAP_D: src = e->d; count = e->m; break;
-    case ELLP_TAP_RHO: src = e->rho; count = e->m; break;
     case ELLP_TAP_KEY: src = e->key; count = e->nN; break;
     case ELLP_TAP_BINV: {
         // row-major m x m without the padding
         count = e->m * e->m;
         if (count > cap) return ELLP_ERR_ARG;
-        if (hipMemcpy2DAsync(dst, sizeof(double) * (size_t)e->m, e->W, sizeof(double) * (size_t)e->ld,
+        if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess)
+            return ELLP_ERR_DEVICE;
+        if (hipMemcpy2DAsync(dst, sizeof(double) * (size_t)e->m, e->h_st->cur ? e->W2 : e->W, sizeof(double) * (size_t)e->ld,
                              sizeof(double) * (size_t)e->m, (size_t)e->m, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
             return ELLP_ERR_DEVICE;
         if (hipStreamSynchronize(e->stream) != hipSuccess) return ELLP_ERR_DEVICE;
@@ -1663,8 +1780,8 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
 double ellp_engine_inverse_residual(ellp_engine *e) {
     if (!e) return NAN;
     if (hipSetDevice(e->device) != hipSuccess) return NAN;
-    hipLaunchKernelGGL(k_inv_residual, dim3((unsigned)e->m), dim3(256), 0, e->stream, e->W, e->A_B, e->m, e->ld,
-                       e->resid);
+    hipLaunchKernelGGL(k_inv_residual, dim3((unsigned)e->m), dim3(256), 0, e->stream, e->W, e->W2, e->st, e->A_B,
+                       e->m, e->ld, e->resid);
     std::vector<double> h((size_t)e->m);
     if (hipMemcpyAsync(h.data(), e->resid, sizeof(double) * (size_t)e->m, hipMemcpyDeviceToHost, e->stream) != hipSuccess)
         return NAN;

@@ -164,7 +164,7 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index,
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
 enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,
-       ELLP_TAP_ALPHA = 5, ELLP_TAP_RHO = 6 };
+       ELLP_TAP_ALPHA = 5 };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
 /* Forces a refactorisation of B^-1 now (used by tests and by the drift monitor). */
