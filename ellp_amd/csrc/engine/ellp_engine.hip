@@ -15,18 +15,33 @@
 //   A_B  : ld x m  column-major  — basic columns (only read by the refactorisation).
 //   W[2] : m x ld  ROW-major     — B^-1, two buffers.  Row-major so that FTRAN (d_i = W[i,:].a_q)
 //          is one coalesced dot product per row, the dual's rho = row r of B^-1 is one
-//          contiguous row, and the eta update streams whole rows.  The eta update reads buffer
-//          `cur^1` and writes buffer `cur` (ping-pong): no block ever reads a row another block
-//          is overwriting, and the pivot row needs no staging copy.
-//   u, rho, d, x, c_B, c_N, keys : vectors.
+//          contiguous row, and the eta update streams whole rows.  The eta update reads one
+//          buffer and writes the other (ping-pong): no block ever reads a row another block is
+//          overwriting, and the pivot row needs no staging copy.
+//   u, d, x, c_B, c_N, keys, lambda_i : vectors.
+//
+// Launch structure — three launches per simplex iteration:
+//   primal:  k_price<.,0>   r = c_N - A_N^T u, Dantzig keys, per-block maxima      (HBM-bound)
+//            k_ftran2<0>    [entering fold] + d = +-B^-1 a_q + lambda_i per row    (HBM-bound)
+//            k_update2<0>   [ratio-test fold] + eta update of B^-1 + bookkeeping   (HBM-bound)
+//   dual:    k_price<.,1>   alpha = A_N^T rho, ratios d_j/alpha_j, per-block argmin
+//            k_ftran2<1>    [argmin over blocks] + alpha_q = B^-1 a_q
+//            k_update2<1>   eta update + d/y/x updates + next leaving row
+// The bracketed decision steps are O(m) / O(|N|/cpb) folds.  A separate single-block kernel for
+// each costs ~10 us of launch + cold-miss latency (measured), so instead EVERY block of the
+// following bandwidth kernel recomputes the same fold in its prologue from inputs that no block
+// of that kernel writes (deterministic => all blocks agree), and block 0 alone commits the
+// decision to the state for later kernels.  Rule kept throughout: a kernel never reads a state
+// field that one of its own blocks writes (except `status`, where a late reader that sees the
+// final status simply exits — the result it would have produced is unused).
 //
 // There is no CPU path in this file: without a HIP device every entry point returns
 // ELLP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
-#include <cstdarg>
 #include <cmath>
+#include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -41,23 +56,25 @@ constexpr int ST_RUNNING = 100;
 constexpr int WAVE = 64;
 
 struct DevState {
-    int32_t status;     // ST_RUNNING or an ellp_status
-    int32_t do_update;  // the ratio/dupdate kernel asks for an eta update of W
-    int32_t at_lower;   // entering variable sits at its lower bound (FTRAN result is negated)
-    int32_t side;       // bound the leaving variable goes to
+    // ---- live words
+    int32_t status;      // ST_RUNNING or an ellp_status
     int32_t nan_flag;
-    int32_t panic_code; // which assert of the reference fired
-    int32_t cur;        // index of the B^-1 buffer that is current
-    int32_t swap_cols;  // the eta update also swaps A_B[:,r] <-> A_N[:,q] (not during refactorisation)
-    int64_t q;          // entering position in N
-    int64_t r;          // leaving position in B, -1 = none
-    int64_t refk;       // refactorisation step
-    double lambda;
-    double rq;          // reduced cost of the entering column
-    double d_r;         // d[r] (signed as stored in d)
-    double alpha_r;     // (B^-1 a_q)_r
-    double ucoef;       // rq / alpha_r : u += ucoef * rho
-    double delta, theta_d, theta_p, obj;  // dual
+    int32_t panic_code;  // which assert of the reference fired
+    int32_t cur;         // index of the current B^-1 buffer (written by k_update2 block 0 / refactor)
+    // ---- snapshot written by k_ftran2 block 0, read by k_update2 (which never writes it)
+    int32_t s_cur, s_at_lower, s_side, s_pad;
+    int64_t s_q, s_jq, s_r;
+    double s_rq, s_lambda0, s_delta, s_theta_d;
+    // ---- dual: leaving row for the coming iteration (written by k_dleave / k_update2<1> block 0)
+    int64_t lr;
+    double ldelta;
+    int32_t lside, l_pad;
+    // ---- refactorisation (single-block k_ref_pick -> k_ref_update)
+    int32_t do_update, r_pad;
+    int64_t r, refk;
+    double d_r, alpha_r;
+    // ---- results
+    double lambda, obj;
     unsigned long long iters, pivots, flips;
 };
 
@@ -72,17 +89,12 @@ __device__ __forceinline__ double wave_min(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
-}
 
 // ------------------------------------------------------------------ pricing
-// r_j = c_N[j] - A_N[:,j].u  for every nonbasic column (primal…:189), fused with the
-// eligibility filter / Dantzig key of pivot() (primal…:253-270).
-// MODE 1 (dual): alpha_j = A_N[:,j].rho (dual…:255) fused with the dual ratio key
-// d[N_j]/alpha_j over eligible columns (dual…:263-278) and a per-block first-argmin.
+// MODE 0 (primal): r_j = c_N[j] - A_N[:,j].u for every nonbasic column (primal…:189), fused with
+// the eligibility filter / Dantzig key of pivot() (primal…:253-270) and a per-block key maximum.
+// MODE 1 (dual): alpha_j = A_N[:,j].rho (dual…:255) with rho = row lr of B^-1, fused with the dual
+// ratio d[N_j]/alpha_j over eligible columns (dual…:263-278) and a per-block FIRST argmin.
 //
 // One block = 256 threads = 4 waves streams `cpb` consecutive columns.  The 256 threads stride
 // down a column 16 B per lane (perfectly coalesced 4 KiB per block-instruction); the slice of
@@ -91,16 +103,16 @@ __device__ __forceinline__ double wave_max(double v) {
 // loads outstanding.  HBM-bound: 8*ld bytes per column, 2 flops per 8 bytes.
 struct PriceArgs {
     const double *A_N;
-    const double *W0, *W1; // dual: rho = row st->r of the current B^-1 buffer (dual…:248-253)
-    const double *u;      // primal: u
-    const double *c_N;    // primal only
+    const double *W0, *W1;  // dual: rho = row st->lr of the current B^-1 buffer (dual…:248-253)
+    const double *u;        // primal: u
+    const double *c_N;      // primal only
     const uint8_t *Nb;
     const int64_t *N_index;
-    const double *dd;     // dual: reduced costs d (indexed by variable)
-    double *r;            // primal: r ; dual: alpha
-    double *key;          // primal: Dantzig key (or -inf)
-    double *blockkey;     // per-block max (primal) / min (dual)
-    int64_t *blockpos;    // dual: position of the block's first minimum
+    const double *dd;       // dual: reduced costs d (indexed by variable)
+    double *r;              // primal: r ; dual: alpha
+    double *key;            // primal: Dantzig key (or -inf)
+    double *blockkey;       // per-block max (primal) / min (dual)
+    int64_t *blockpos;      // dual: position of the block's first minimum
     DevState *st;
     int64_t ld, nN;
     int cpb;
@@ -112,11 +124,26 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     __shared__ double s_part[2][4][4];
     __shared__ double s_k[4];
     __shared__ long long s_p[4];
-    if (a.st->status != ST_RUNNING) return;
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t half = a.ld >> 1;
-    const double2 *u2 = reinterpret_cast<const double2 *>(
-        MODE == 0 ? a.u : ((a.st->cur ? a.W1 : a.W0) + a.st->r * a.ld));
+    double sgn = 1.0;
+    const double2 *u2;
+    if (MODE == 0) {
+        u2 = reinterpret_cast<const double2 *>(a.u);
+    } else {
+        const int64_t lr = st->lr;
+        if (lr < 0) {  // no primal-infeasible basic: optimal (dual…:243-246)
+            if (blockIdx.x == 0 && tid == 0) {
+                st->iters += 1;
+                st->status = ELLP_OPTIMAL;
+            }
+            return;
+        }
+        sgn = (st->ldelta < 0.0) ? -1.0 : 1.0;
+        u2 = reinterpret_cast<const double2 *>((st->cur ? a.W1 : a.W0) + lr * a.ld);
+    }
     double2 ur[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -125,8 +152,6 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     }
     const int64_t j0 = (int64_t)blockIdx.x * a.cpb;
     const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
-    double sgn = 1.0;
-    if (MODE == 1) sgn = (a.st->delta < 0.0) ? -1.0 : 1.0;
     double best = (MODE == 0) ? -INFINITY : INFINITY;
     long long bestpos = -1;
     int buf = 0;
@@ -170,7 +195,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
                 const double rj = a.c_N[jj] - dot;
                 double key = -INFINITY;
                 if (rj != rj) {
-                    a.st->nan_flag = 1;
+                    st->nan_flag = 1;
                 } else if (!(fabs(rj) < a.eps)) {
                     const bool pos = rj > 0.0;
                     if (pos && nb == ELLP_NB_UPPER) key = rj;
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
                 else keep = true;
                 if (keep) {
                     const double ratio = a.dd[a.N_index[jj]] / al;
-                    if (ratio != ratio) a.st->nan_flag = 1;
+                    if (ratio != ratio) st->nan_flag = 1;
                     if (bestpos < 0 || ratio < best) {  // strict '<' keeps the FIRST minimum
                         best = ratio;
                         bestpos = jj;
@@ -228,93 +253,37 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ primal entering selection
+// ------------------------------------------------------------------ primal entering fold (one wave)
 // Exact emulation of the reference's sequential `max_by` fold (primal…:271-287): candidate
 // (key, N.index) replaces the accumulator iff NOT(|acc-key| >= EPS ? acc > key : acc.index >
-// index).  The comparator is not transitive, so the fold cannot be turned into a tree
-// reduction; instead ONE wave walks the pricing blocks in position order and uses ballots to
-// skip everything that cannot change the accumulator: a block whose maximum key is
-// <= acc - EPS holds no such element.  Work is O(#blocks/64 + #accumulator changes).
-// The whole 256-thread block first stages the block maxima (and, when they fit, all keys and
-// variable indices) into LDS with independent coalesced loads, so the serial walk never waits
-// on global memory.
-struct SelectArgs {
-    const double *key, *blockkey, *r;
-    const int64_t *N_index;
-    const uint8_t *Nb;
-    DevState *st;
-    int64_t nN;
-    int nblocks, cpb;
-    int stage_keys;  // keys + indices fit in LDS
-    double eps;
-};
-
-__global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    DevState *st = a.st;
-    if (st->status != ST_RUNNING) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    double *s_bk = reinterpret_cast<double *>(smem);
-    double *s_key = s_bk + a.nblocks;
-    int32_t *s_idx = reinterpret_cast<int32_t *>(s_key + (a.stage_keys ? a.nN : 0));
-    for (int b = tid; b < a.nblocks; b += 1024) s_bk[b] = a.blockkey[b];
-    if (a.stage_keys) {
-        // batches of 8 independent loads per thread: one memory round trip per 8192 columns
-        for (int64_t j0 = tid; j0 < a.nN; j0 += 8 * 1024) {
-            double kk[8];
-            long long ii[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t j = j0 + (int64_t)u * 1024;
-                kk[u] = j < a.nN ? a.key[j] : 0.0;
-                ii[u] = j < a.nN ? a.N_index[j] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t j = j0 + (int64_t)u * 1024;
-                if (j < a.nN) {
-                    s_key[j] = kk[u];
-                    s_idx[j] = (int32_t)ii[u];
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (tid >= WAVE) return;
-    if (st->nan_flag) {
-        if (lane == 0) st->status = ELLP_ERR_NAN;
-        return;
-    }
+// index).  The comparator is not transitive, so the fold cannot be a tree reduction; instead a
+// wave walks the pricing blocks in position order and uses ballots to skip everything that
+// cannot change the accumulator: a block whose maximum key is <= acc - EPS holds no such
+// element.  Work is O(#blocks/64 + #accumulator changes).  s_bk = block maxima staged in LDS.
+__device__ __forceinline__ long long entering_fold(const double *s_bk, int nblocks, int cpb, int64_t nN,
+                                                   const double *key, const int64_t *N_index, double eps,
+                                                   int lane) {
     bool have = false;
     double racc = 0.0;
     long long iacc = 0, qacc = -1;
-    for (int g0 = 0; g0 < a.nblocks; g0 += WAVE) {
-        const double bm = (g0 + lane < a.nblocks) ? s_bk[g0 + lane] : -INFINITY;
+    for (int g0 = 0; g0 < nblocks; g0 += WAVE) {
+        const double bm = (g0 + lane < nblocks) ? s_bk[g0 + lane] : -INFINITY;
         int from = 0;
         for (;;) {
-            const bool pred = lane >= from && bm > -INFINITY && (!have || bm > racc - a.eps);
+            const bool pred = lane >= from && bm > -INFINITY && (!have || bm > racc - eps);
             const unsigned long long mask = __ballot(pred);
             if (!mask) break;
             const int bl = __ffsll((long long)mask) - 1;
-            const int64_t jb = (int64_t)(g0 + bl) * a.cpb;
+            const int64_t jb = (int64_t)(g0 + bl) * cpb;
             const int64_t j = jb + lane;
-            const bool valid = lane < a.cpb && j < a.nN;
-            double k = -INFINITY;
-            long long idx = 0;
-            if (valid) {
-                if (a.stage_keys) {
-                    k = s_key[j];
-                    idx = s_idx[j];
-                } else {
-                    k = a.key[j];
-                    idx = a.N_index[j];
-                }
-            }
+            const bool valid = lane < cpb && j < nN;
+            const double k = valid ? key[j] : -INFINITY;
+            const long long idx = valid ? N_index[j] : 0;
             int efrom = 0;
             for (;;) {
                 bool ev = lane >= efrom && k > -INFINITY;
                 if (ev && have) {
-                    const bool acc_greater = (fabs(racc - k) >= a.eps) ? (racc > k) : (iacc > idx);
+                    const bool acc_greater = (fabs(racc - k) >= eps) ? (racc > k) : (iacc > idx);
                     ev = !acc_greater;
                 }
                 const unsigned long long em = __ballot(ev);
@@ -329,47 +298,118 @@ __global__ __launch_bounds__(1024) void k_select(SelectArgs a) {
             from = bl + 1;
         }
     }
-    if (lane == 0) {
-        st->do_update = 0;
-        if (!have) {
-            st->iters += 1;
-            st->status = ELLP_OPTIMAL;  // primal…:289-292
-        } else {
-            st->q = qacc;
-            st->rq = a.r[qacc];
-            st->at_lower = (a.Nb[qacc] == ELLP_NB_LOWER) ? 1 : 0;
-        }
-    }
+    return qacc;
 }
 
-// ------------------------------------------------------------------ FTRAN
+// ------------------------------------------------------------------ FTRAN (+ decision prologue)
 // d = +-B^-1 a_q (primal…:295-300, dual…:294): one wave per row of the row-major W, 16 B per
-// lane, a_q re-read through L1/L2 (it is 8*ld bytes, W is 8*m*ld).  mode 0: column q of A_N,
-// sign from st->at_lower.  mode 1 (refactorisation): column st->refk of A_B, sign +.
-struct FtranArgs {
-    const double *W0, *W1;
-    const double *A_N, *A_B;
-    double *d;
+// lane, eight 16-byte loads per lane in flight; a_q (8*ld bytes) is re-read through L1/L2.
+// Prologue, every block: MODE 0 the entering fold over the pricing output, MODE 1 the dual
+// ratio argmin over the per-block minima (dual…:279, min_by keeps the FIRST minimum).
+// Epilogue MODE 0: the wave that produced d_i also evaluates the ratio lambda_i of basic row i
+// by bound kind (primal…:320-367) so that k_update2's fold only reads three flat arrays.
+struct Ftran2Args {
+    const double *W0, *W1, *A_N;
+    const double *key, *blockkey, *r;
+    const int64_t *blockpos;
+    const int64_t *N_index, *B_index;
+    const uint8_t *Nb, *kind;
+    const double *x, *lb, *ub;
+    double *d, *lam;
+    int32_t *bidx;
+    uint8_t *dpos;
     DevState *st;
-    int64_t m, ld;
-    int mode;
+    int64_t m, ld, nN;
+    int nblocks, cpb;
+    double eps;
 };
 
-__global__ __launch_bounds__(256) void k_ftran(FtranArgs a) {
-    if (a.st->status != ST_RUNNING) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    const int64_t half = a.ld >> 1;
-    const double *W = a.st->cur ? a.W1 : a.W0;
-    const double2 *col;
-    double sgn = 1.0;
-    if (a.mode == 0) {
-        col = reinterpret_cast<const double2 *>(a.A_N + a.st->q * a.ld);
-        sgn = a.st->at_lower ? -1.0 : 1.0;
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ long long s_q;
+    __shared__ double s_wk[4];
+    __shared__ long long s_wp[4];
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nan_flag = st->nan_flag;
+    const int cur = st->cur;
+    double theta_d = 0.0;
+    if (MODE == 0) {
+        double *s_bk = reinterpret_cast<double *>(smem);
+        for (int b0 = tid; b0 < a.nblocks; b0 += 4 * 256) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (b0 + 256 * u < a.nblocks) ? a.blockkey[b0 + 256 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (b0 + 256 * u < a.nblocks) s_bk[b0 + 256 * u] = v[u];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const long long q = entering_fold(s_bk, a.nblocks, a.cpb, a.nN, a.key, a.N_index, a.eps, lane);
+            if (lane == 0) s_q = q;
+        }
+        __syncthreads();
     } else {
-        col = reinterpret_cast<const double2 *>(a.A_B + a.st->refk * a.ld);
+        if (st->lr < 0) return;  // k_price<.,1> block 0 has already reported Optimal
+        double bk = INFINITY;
+        long long bp = -1;
+        for (int b = tid; b < a.nblocks; b += 256) {
+            const long long p = a.blockpos[b];
+            if (p < 0) continue;
+            const double k = a.blockkey[b];
+            if (bp < 0 || k < bk || (k == bk && p < bp)) {
+                bk = k;
+                bp = p;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ok = __shfl_xor(bk, o);
+            const long long op = __shfl_xor(bp, o);
+            if (op >= 0 && (bp < 0 || ok < bk || (ok == bk && op < bp))) {
+                bk = ok;
+                bp = op;
+            }
+        }
+        if (lane == 0) {
+            s_wk[wave] = bk;
+            s_wp[wave] = bp;
+        }
+        __syncthreads();
+        bk = s_wk[0];
+        bp = s_wp[0];
+        for (int w = 1; w < 4; ++w)
+            if (s_wp[w] >= 0 && (bp < 0 || s_wk[w] < bk || (s_wk[w] == bk && s_wp[w] < bp))) {
+                bk = s_wk[w];
+                bp = s_wp[w];
+            }
+        if (tid == 0) s_q = bp;
+        theta_d = (st->ldelta < 0.0) ? -bk : bk;  // dual…:286-289
+        __syncthreads();
     }
+    const long long q = s_q;
+    if (nan_flag) {
+        if (blockIdx.x == 0 && tid == 0) st->status = ELLP_ERR_NAN;
+        return;
+    }
+    if (q < 0) {
+        if (blockIdx.x == 0 && tid == 0) {
+            st->iters += 1;
+            st->status = (MODE == 0) ? ELLP_OPTIMAL      // primal…:289-292
+                                     : ELLP_INFEASIBLE;  // dual unbounded, dual…:281-284
+        }
+        return;
+    }
+    const int at_lower = (MODE == 0) ? (a.Nb[q] == ELLP_NB_LOWER ? 1 : 0) : 0;
+    const double sgn = at_lower ? -1.0 : 1.0;
+    const double *W = cur ? a.W1 : a.W0;
+    const double2 *col = reinterpret_cast<const double2 *>(a.A_N + q * a.ld);
+    const int64_t half = a.ld >> 1;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t i = wave_global; i < a.m; i += nwaves) {
         const double2 *row = reinterpret_cast<const double2 *>(W + i * a.ld);
         double acc0 = 0.0, acc1 = 0.0;
@@ -387,290 +427,141 @@ __global__ __launch_bounds__(256) void k_ftran(FtranArgs a) {
                 acc1 = fma(w[u].y, c[u].y, acc1);
             }
         }
-        const double s = wave_sum(acc0 + acc1);
-        if (lane == 0) a.d[i] = sgn * s;
-    }
-}
-
-// ------------------------------------------------------------------ primal ratio test + pivot bookkeeping
-// One 1024-thread block.  Phase A (all waves): lambda_i per basic row by bound kind
-// (primal…:320-367) into LDS (or a global scratch when m is too large) + per-64 minima.
-// Phase B (wave 0): exact emulation of the sequential fold (primal…:379-399), including the
-// quirk that `new_basic_index` is only written in the tie branch; ballots skip every chunk
-// whose minimum cannot touch the running lambda.  Phase C (all waves): x update
-// (primal…:408-417), index / cost swap (primal…:205-221) or bound flip (:223-231); the column
-// swap and the eta update of B^-1 are left to k_update, which this kernel arms by flipping the
-// current-buffer index.
-struct RatioArgs {
-    double *c_B, *c_N, *x;
-    const double *d, *lb, *ub;
-    const uint8_t *kind;
-    int64_t *B_index, *N_index;
-    uint8_t *Nb;
-    double *g_lam;     // global scratch (m) when LDS is too small
-    int32_t *g_bidx;
-    uint8_t *g_dpos;
-    DevState *st;
-    int64_t m;
-    int use_lds;
-    double eps;
-};
-
-template <int RE>
-__global__ __launch_bounds__(1024) void k_ratio(RatioArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ double s_lambda;
-    __shared__ long long s_nb;
-    __shared__ int s_side;
-    DevState *st = a.st;
-    if (st->status != ST_RUNNING) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m = a.m;
-    const int nchunks = (int)((m + 63) >> 6);
-    double *chunkmin = reinterpret_cast<double *>(smem);
-    double *lam;
-    int32_t *bidx;
-    uint8_t *dpos;
-    if (a.use_lds) {
-        lam = chunkmin + nchunks;
-        bidx = reinterpret_cast<int32_t *>(lam + m);
-        dpos = reinterpret_cast<uint8_t *>(bidx + m);
-    } else {
-        lam = a.g_lam;
-        bidx = a.g_bidx;
-        dpos = a.g_dpos;
-    }
-    const int64_t q = st->q;
-    const int64_t jq = a.N_index[q];
-    const int at_lower = st->at_lower;
-    const double eps = a.eps;
-    const int kq = a.kind[jq];
-    const double lbq = a.lb[jq], ubq = a.ub[jq];
-
-    // ---- phase A: thread t owns basic rows t, t+1024, ... (RE of them), held in registers so
-    // that the two dependent gathers (B_index -> x/bounds) are one round trip each.
-    double di[RE], xi[RE];
-    int32_t bi[RE];
-#pragma unroll
-    for (int k = 0; k < RE; ++k) {
-        const int64_t i = tid + 1024 * k;
-        di[k] = i < m ? a.d[i] : 0.0;
-        bi[k] = i < m ? (int32_t)a.B_index[i] : 0;
-    }
-    double lbi[RE], ubi[RE];
-    int kd[RE];
-#pragma unroll
-    for (int k = 0; k < RE; ++k) {
-        const int64_t i = tid + 1024 * k;
-        xi[k] = i < m ? a.x[bi[k]] : 0.0;
-        kd[k] = i < m ? a.kind[bi[k]] : ELLP_BOUND_FREE;
-        lbi[k] = i < m ? a.lb[bi[k]] : 0.0;
-        ubi[k] = i < m ? a.ub[bi[k]] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < RE; ++k) {
-        const int64_t i = tid + 1024 * k;
-        const int c = wave + 16 * k;
-        if (c >= nchunks) continue;  // wave-uniform
-        double li = INFINITY;
-        if (i < m && !(fabs(di[k]) < eps)) {
-            const double d_i = di[k], x_i = xi[k];
-            if (kd[k] == ELLP_BOUND_FREE) {
-                li = INFINITY;
-            } else if (kd[k] == ELLP_BOUND_LOWER) {
-                if (d_i > 0.0) li = INFINITY;
-                else if (x_i > lbi[k]) li = (lbi[k] - x_i) / d_i;
-                else li = 0.0;
-            } else if (kd[k] == ELLP_BOUND_UPPER) {
-                if (d_i > 0.0) li = (x_i < ubi[k]) ? (ubi[k] - x_i) / d_i : 0.0;
-                else li = INFINITY;
-            } else if (kd[k] == ELLP_BOUND_TWOSIDED) {
-                if (d_i > 0.0) li = (x_i < ubi[k]) ? (ubi[k] - x_i) / d_i : 0.0;
-                else if (x_i < lbi[k]) li = (lbi[k] - x_i) / d_i;  // quirk Q1 (primal…:359)
-                else li = 0.0;
-            } else {
-                li = 0.0;  // Fixed
-            }
-            if (li != li) st->nan_flag = 1;
-        }
-        if (i < m) {
-            lam[i] = li;
-            bidx[i] = bi[k];
-            dpos[i] = di[k] > 0.0 ? 1 : 0;
-        }
-        const double cm = wave_min(li);
-        if (lane == 0) chunkmin[c] = cm;
-    }
-    __syncthreads();
-
-    // ---- phase B
-    if (wave == 0) {
-        double lambda;
-        if (kq == ELLP_BOUND_TWOSIDED) lambda = ubq - lbq;  // primal…:305-311
-        else if (kq == ELLP_BOUND_FIXED) lambda = 0.0;
-        else lambda = INFINITY;
-        long long nb = -1;
-        int side = ELLP_NB_LOWER;
-        bool have_nbi = false;
-        int32_t nbi = 0;
-        for (int g0 = 0; g0 < nchunks; g0 += WAVE) {
-            const double cm = (g0 + lane < nchunks) ? chunkmin[g0 + lane] : INFINITY;
-            int from = 0;
-            for (;;) {
-                const bool pred = lane >= from && cm < lambda + eps;
-                const unsigned long long mask = __ballot(pred);
-                if (!mask) break;
-                const int cl = __ffsll((long long)mask) - 1;
-                const int64_t i = (int64_t)(g0 + cl) * 64 + lane;
-                const double li = (i < m) ? lam[i] : INFINITY;
-                const int32_t b_i = (i < m) ? bidx[i] : 0;
-                const int dp = (i < m) ? dpos[i] : 0;
-                int efrom = 0;
-                for (;;) {
-                    const bool strict = li < lambda - eps;
-                    const bool tie = !strict && fabs(li - lambda) < eps && (!have_nbi || b_i < nbi);
-                    const bool ev = lane >= efrom && (strict || tie);
-                    const unsigned long long em = __ballot(ev);
-                    if (!em) break;
-                    const int l = __ffsll((long long)em) - 1;
-                    const int was_tie = __shfl((int)tie, l);
-                    lambda = __shfl(li, l);
-                    nb = (long long)(g0 + cl) * 64 + l;
-                    side = __shfl(dp, l) ? ELLP_NB_UPPER : ELLP_NB_LOWER;
-                    if (was_tie) {
-                        have_nbi = true;
-                        nbi = __shfl(b_i, l);
-                    }
-                    efrom = l + 1;
-                }
-                from = cl + 1;
-            }
-        }
+        const double di = sgn * wave_sum(acc0 + acc1);
         if (lane == 0) {
-            s_lambda = lambda;
-            s_nb = nb;
-            s_side = side;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase C
-    const double lambda = s_lambda;
-    const long long nbp = s_nb;
-    if (st->nan_flag) {
-        if (tid == 0) st->status = ELLP_ERR_NAN;
-        return;
-    }
-    if (!(lambda >= 0.0)) {  // primal…:402
-        if (tid == 0) {
-            st->panic_code = 402;
-            st->status = ELLP_ERR_PANIC;
-        }
-        return;
-    }
-    if (isinf(lambda)) {  // primal…:404-406
-        if (tid == 0) {
-            st->iters += 1;
-            st->status = ELLP_UNBOUNDED;
-        }
-        return;
-    }
-    if (lambda > 0.0) {  // primal…:408-417
-#pragma unroll
-        for (int k = 0; k < RE; ++k) {
-            const int64_t i = tid + 1024 * k;
-            if (i < m) a.x[bi[k]] = xi[k] + lambda * di[k];
-        }
-        if (tid == 0) {
-            if (at_lower) a.x[jq] = a.x[jq] + lambda;
-            else a.x[jq] = a.x[jq] - lambda;
-        }
-    }
-    if (tid == 0) {
-        if (nbp >= 0) {
-            const int64_t r = nbp;
-            const double tc = a.c_N[q];
-            a.c_N[q] = a.c_B[r];
-            a.c_B[r] = tc;
-            a.N_index[q] = a.B_index[r];
-            a.B_index[r] = jq;
-            a.Nb[q] = (uint8_t)s_side;
-            const double dr = a.d[r];
-            const double alpha_r = at_lower ? -dr : dr;
-            st->r = r;
-            st->side = s_side;
-            st->lambda = lambda;
-            st->d_r = dr;
-            st->alpha_r = alpha_r;
-            st->ucoef = st->rq / alpha_r;
-            st->swap_cols = 1;
-            st->cur ^= 1;  // k_update reads buffer cur^1 and writes buffer cur
-            st->do_update = 1;
-            st->pivots += 1;
-            st->iters += 1;
-        } else {
-            const int nbq = a.Nb[q];
-            st->r = -1;
-            st->lambda = lambda;
-            st->do_update = 0;
-            if (nbq == ELLP_NB_LOWER) a.Nb[q] = ELLP_NB_UPPER;
-            else if (nbq == ELLP_NB_UPPER) a.Nb[q] = ELLP_NB_LOWER;
-            else {
-                st->panic_code = 229;  // "pivot should have been unbounded"
-                st->status = ELLP_ERR_PANIC;
+            a.d[i] = di;
+            if (MODE == 0) {
+                const int64_t bi = a.B_index[i];
+                double li = INFINITY;
+                if (!(fabs(di) < a.eps)) {
+                    const double xi = a.x[bi];
+                    const int k = a.kind[bi];
+                    const double lbi = a.lb[bi], ubi = a.ub[bi];
+                    if (k == ELLP_BOUND_FREE) {
+                        li = INFINITY;
+                    } else if (k == ELLP_BOUND_LOWER) {
+                        if (di > 0.0) li = INFINITY;
+                        else if (xi > lbi) li = (lbi - xi) / di;
+                        else li = 0.0;
+                    } else if (k == ELLP_BOUND_UPPER) {
+                        if (di > 0.0) li = (xi < ubi) ? (ubi - xi) / di : 0.0;
+                        else li = INFINITY;
+                    } else if (k == ELLP_BOUND_TWOSIDED) {
+                        if (di > 0.0) li = (xi < ubi) ? (ubi - xi) / di : 0.0;
+                        else if (xi < lbi) li = (lbi - xi) / di;  // quirk Q1 (primal…:359)
+                        else li = 0.0;
+                    } else {
+                        li = 0.0;  // Fixed
+                    }
+                    if (li != li) st->nan_flag = 1;
+                }
+                a.lam[i] = li;
+                a.bidx[i] = (int32_t)bi;
+                a.dpos[i] = di > 0.0 ? 1 : 0;
             }
-            st->flips += 1;
-            st->iters += 1;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {  // commit the decision for k_update2
+        st->s_cur = cur;
+        st->s_q = q;
+        st->s_at_lower = at_lower;
+        if (MODE == 0) {
+            const int64_t jq = a.N_index[q];
+            st->s_jq = jq;
+            st->s_rq = a.r[q];
+            const int k = a.kind[jq];  // primal…:305-311
+            st->s_lambda0 = (k == ELLP_BOUND_TWOSIDED) ? a.ub[jq] - a.lb[jq] : (k == ELLP_BOUND_FIXED ? 0.0 : INFINITY);
+        } else {
+            st->s_jq = a.N_index[q];
+            st->s_r = st->lr;
+            st->s_delta = st->ldelta;
+            st->s_side = st->lside;
+            st->s_theta_d = theta_d;
         }
     }
 }
 
-// ------------------------------------------------------------------ eta update of B^-1
-// dst[i,:] = src[i,:] - (d_i/d_r) * src[r,:]   (i != r),   dst[r,:] = src[r,:] / alpha_r,
-// src = buffer cur^1, dst = buffer cur.  16*m*ld bytes (read + write).  The last block also
-// swaps the columns A_B[:,r] <-> A_N[:,q] (primal…:211-217, dual…:325-331) and carries the O(m)
-// BTRAN update u += (r_q/alpha_r) * rho when the engine runs in incremental-u mode.
-struct UpdateArgs {
-    double *W0, *W1;
-    const double *d;
-    double *u, *A_N, *A_B;
-    DevState *st;
-    int64_t m, ld;
-    int rows_per_block;
-    int update_u;
+// ------------------------------------------------------------------ primal ratio-test fold (one wave)
+// Exact emulation of the sequential fold of primal…:379-399, including the quirk that
+// `new_basic_index` is only written in the tie branch.  chunkmin[c] = min lambda over rows
+// 64c..64c+63; a chunk whose minimum is >= lambda + EPS cannot change the state.
+struct RatioResult {
+    double lambda;
+    long long nb;
+    int side;
 };
+__device__ __forceinline__ RatioResult ratio_fold(const double *chunkmin, int nchunks, int64_t m, const double *lam,
+                                                  const int32_t *bidx, const uint8_t *dpos, double lambda0,
+                                                  double eps, int lane) {
+    double lambda = lambda0;
+    long long nb = -1;
+    int side = ELLP_NB_LOWER;
+    bool have_nbi = false;
+    int32_t nbi = 0;
+    for (int g0 = 0; g0 < nchunks; g0 += WAVE) {
+        const double cm = (g0 + lane < nchunks) ? chunkmin[g0 + lane] : INFINITY;
+        int from = 0;
+        for (;;) {
+            const bool pred = lane >= from && cm < lambda + eps;
+            const unsigned long long mask = __ballot(pred);
+            if (!mask) break;
+            const int cl = __ffsll((long long)mask) - 1;
+            const int64_t i = (int64_t)(g0 + cl) * 64 + lane;
+            const double li = (i < m) ? lam[i] : INFINITY;
+            const int32_t b_i = (i < m) ? bidx[i] : 0;
+            const int dp = (i < m) ? dpos[i] : 0;
+            int efrom = 0;
+            for (;;) {
+                const bool strict = li < lambda - eps;
+                const bool tie = !strict && fabs(li - lambda) < eps && (!have_nbi || b_i < nbi);
+                const bool ev = lane >= efrom && (strict || tie);
+                const unsigned long long em = __ballot(ev);
+                if (!em) break;
+                const int l = __ffsll((long long)em) - 1;
+                const int was_tie = __shfl((int)tie, l);
+                lambda = __shfl(li, l);
+                nb = (long long)(g0 + cl) * 64 + l;
+                side = __shfl(dp, l) ? ELLP_NB_UPPER : ELLP_NB_LOWER;
+                if (was_tie) {
+                    have_nbi = true;
+                    nbi = __shfl(b_i, l);
+                }
+                efrom = l + 1;
+            }
+            from = cl + 1;
+        }
+    }
+    return RatioResult{lambda, nb, side};
+}
 
-__global__ __launch_bounds__(256) void k_update(UpdateArgs a) {
-    const DevState *st = a.st;
-    if (st->status != ST_RUNNING || !st->do_update) return;
-    const int tid = threadIdx.x;
-    const int64_t half = a.ld >> 1;
-    const int64_t r = st->r;
-    const double d_r = st->d_r, alpha_r = st->alpha_r;
-    const double *src = st->cur ? a.W0 : a.W1;
-    double *dst = st->cur ? a.W1 : a.W0;
-    const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
-    // UPD_ROWS rows per pass: every thread keeps UPD_ROWS independent 16-byte loads in flight
-    // and re-uses its rho chunk for all of them.
+// rows [row0, row0+nrows) of the eta update:
+// dst[i,:] = src[i,:] - (d_i/d_r) * src[r,:]   (i != r),   dst[r,:] = src[r,:] / alpha_r.
+// Four rows per pass: every thread keeps four independent 16-byte loads in flight and re-uses
+// its chunk of the pivot row for all of them.
+__device__ __forceinline__ void eta_update_rows(const double *src, double *dst, int64_t m, int64_t ld, int64_t r,
+                                                const double *d, double d_r, double alpha_r, int64_t row0,
+                                                int nrows, int tid) {
     constexpr int UPD_ROWS = 4;
-    for (int rr = 0; rr < a.rows_per_block; rr += UPD_ROWS) {
-        const int64_t i0 = (int64_t)blockIdx.x * a.rows_per_block + rr;
-        if (i0 >= a.m) break;
+    const int64_t half = ld >> 1;
+    const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * ld);
+    for (int rr = 0; rr < nrows; rr += UPD_ROWS) {
+        const int64_t i0 = row0 + rr;
+        if (i0 >= m) break;
         double f[UPD_ROWS];
         int64_t ii[UPD_ROWS];
 #pragma unroll
         for (int k = 0; k < UPD_ROWS; ++k) {
             const int64_t i = i0 + k;
-            const bool ok = i < a.m && rr + k < a.rows_per_block;
+            const bool ok = i < m && rr + k < nrows;
             ii[k] = ok ? i : -1;
-            f[k] = (ok && i != r) ? -(a.d[i] / d_r) : 0.0;
+            f[k] = (ok && i != r) ? -(d[i] / d_r) : 0.0;
         }
         for (int64_t t = tid; t < half; t += 256) {
             const double2 p = rho2[t];
             double2 w[UPD_ROWS];
 #pragma unroll
             for (int k = 0; k < UPD_ROWS; ++k)
-                if (ii[k] >= 0) w[k] = reinterpret_cast<const double2 *>(src + ii[k] * a.ld)[t];
+                if (ii[k] >= 0) w[k] = reinterpret_cast<const double2 *>(src + ii[k] * ld)[t];
 #pragma unroll
             for (int k = 0; k < UPD_ROWS; ++k) {
                 if (ii[k] < 0) continue;
@@ -681,38 +572,340 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a) {
                     o.x = fma(f[k], p.x, w[k].x);
                     o.y = fma(f[k], p.y, w[k].y);
                 }
-                reinterpret_cast<double2 *>(dst + ii[k] * a.ld)[t] = o;
-            }
-        }
-    }
-    if (blockIdx.x == gridDim.x - 1) {
-        if (a.update_u) {
-            const double cf = st->ucoef;
-            double2 *u2 = reinterpret_cast<double2 *>(a.u);
-            for (int64_t t = tid; t < half; t += 256) {
-                const double2 p = rho2[t];
-                double2 w = u2[t];
-                w.x = fma(cf, p.x, w.x);
-                w.y = fma(cf, p.y, w.y);
-                u2[t] = w;
-            }
-        }
-        if (st->swap_cols) {
-            double2 *cn = reinterpret_cast<double2 *>(a.A_N + st->q * a.ld);
-            double2 *cb = reinterpret_cast<double2 *>(a.A_B + r * a.ld);
-            for (int64_t t = tid; t < half; t += 256) {
-                const double2 x = cn[t];
-                cn[t] = cb[t];
-                cb[t] = x;
+                reinterpret_cast<double2 *>(dst + ii[k] * ld)[t] = o;
             }
         }
     }
 }
 
+__device__ __forceinline__ void swap_columns(double *A_N, double *A_B, int64_t q, int64_t r, int64_t ld, int tid) {
+    double2 *cn = reinterpret_cast<double2 *>(A_N + q * ld);
+    double2 *cb = reinterpret_cast<double2 *>(A_B + r * ld);
+    for (int64_t t = tid; t < (ld >> 1); t += 256) {
+        const double2 x = cn[t];
+        cn[t] = cb[t];
+        cb[t] = x;
+    }
+}
+
+// first basic position (in B order) whose variable violates a bound by more than EPS
+// (dual…:200-236); Free and Fixed basics never leave (quirk Q3)
+__device__ __forceinline__ bool dual_violation(const int64_t *B_index, const double *x, const uint8_t *kind,
+                                               const double *lb, const double *ub, double eps, int64_t i,
+                                               double *delta, int *side) {
+    const int64_t bi = B_index[i];
+    const double xi = x[bi];
+    const int k = kind[bi];
+    if (k == ELLP_BOUND_LOWER) {
+        if (xi < lb[bi] - eps) { *delta = xi - lb[bi]; *side = ELLP_NB_LOWER; return true; }
+    } else if (k == ELLP_BOUND_UPPER) {
+        if (xi > ub[bi] + eps) { *delta = xi - ub[bi]; *side = ELLP_NB_UPPER; return true; }
+    } else if (k == ELLP_BOUND_TWOSIDED) {
+        if (xi > ub[bi] + eps) { *delta = xi - ub[bi]; *side = ELLP_NB_UPPER; return true; }
+        if (xi < lb[bi] - eps) { *delta = xi - lb[bi]; *side = ELLP_NB_LOWER; return true; }
+    }
+    return false;
+}
+// block-wide (256 threads) min-position search; commits lr/ldelta/lside (lr = -1: none)
+__device__ __forceinline__ void find_leaving(const int64_t *B_index, const double *x, const uint8_t *kind,
+                                             const double *lb, const double *ub, double eps, int64_t m, int tid,
+                                             long long *s_tmp /*[4]*/, DevState *st) {
+    const int lane = tid & 63, wave = tid >> 6;
+    long long best = INT64_MAX;
+    double dl;
+    int sd;
+    for (int64_t i = tid; i < m; i += 256) {
+        if (dual_violation(B_index, x, kind, lb, ub, eps, i, &dl, &sd)) {
+            best = i;
+            break;  // increasing i per thread: the first hit is this thread's minimum
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long ob = __shfl_xor(best, o);
+        best = ob < best ? ob : best;
+    }
+    if (lane == 0) s_tmp[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) best = s_tmp[w] < best ? s_tmp[w] : best;
+        if (best == INT64_MAX) {
+            st->lr = -1;
+        } else {
+            double delta = 0.0;
+            int side = 0;
+            dual_violation(B_index, x, kind, lb, ub, eps, best, &delta, &side);
+            st->lr = best;
+            st->ldelta = delta;
+            st->lside = side;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ eta update (+ decision prologue, + bookkeeping)
+// MODE 0 prologue, every block: stage lambda_i / variable index / sign(d_i) (written by
+// k_ftran2) into LDS, per-64 minima, then wave 0 runs the ratio-test fold.  Then all blocks
+// stream their rows of the eta update (16*m*ld bytes read+write in total).  Block 0 finally
+// applies what the reference does after pivot(): x update (primal…:408-417), index / cost /
+// column swap (primal…:205-221) or bound flip (:223-231), and the O(m) BTRAN update
+// u += (r_q/alpha_r) * rho (u = B^-T c_B, primal…:184-187, maintained incrementally).
+// MODE 1: no fold (the leaving row was fixed before pricing); block 0 applies dual…:296-333 and
+// searches the next leaving row.
+struct Update2Args {
+    double *W0, *W1;
+    const double *d;     // primal: d ; dual: alpha_q
+    const double *lam;
+    const int32_t *bidx;
+    const uint8_t *dpos;
+    const double *alpha;  // dual: alpha (per nonbasic position)
+    double *u, *A_N, *A_B, *c_B, *c_N, *x, *y, *dd;
+    const double *lb, *ub;
+    const uint8_t *kind;
+    int64_t *B_index, *N_index;
+    uint8_t *Nb;
+    DevState *st;
+    int64_t m, ld, nN;
+    int rows_per_block;
+    int update_u;
+    int stage_lds;
+    double eps;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_update2(Update2Args a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ double s_lambda;
+    __shared__ long long s_nb;
+    __shared__ int s_side;
+    __shared__ long long s_tmp[4];
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m = a.m;
+    const int cur = st->s_cur;
+    const int64_t q = st->s_q;
+    const double *src = cur ? a.W1 : a.W0;
+    double *dst = cur ? a.W0 : a.W1;
+    int64_t r;
+    double lambda = 0.0;
+    int side = 0;
+    if (MODE == 0) {
+        const int nchunks = (int)((m + 63) >> 6);
+        double *chunkmin = reinterpret_cast<double *>(smem);
+        const double *lam = a.lam;
+        const int32_t *bidx = a.bidx;
+        const uint8_t *dpos = a.dpos;
+        double *l_lam = chunkmin + nchunks;
+        int32_t *l_bidx = reinterpret_cast<int32_t *>(l_lam + (a.stage_lds ? m : 0));
+        uint8_t *l_dpos = reinterpret_cast<uint8_t *>(l_bidx + (a.stage_lds ? m : 0));
+        // each wave takes chunks wave, wave+4, ... ; 4 chunks (independent loads) per pass
+        for (int c0 = wave; c0 < nchunks; c0 += 16) {
+            double v[4];
+            int32_t bi[4];
+            uint8_t dp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = (int64_t)(c0 + 4 * k) * 64 + lane;
+                const bool ok = (c0 + 4 * k) < nchunks && i < m;
+                v[k] = ok ? lam[i] : INFINITY;
+                bi[k] = (ok && a.stage_lds) ? bidx[i] : 0;
+                dp[k] = (ok && a.stage_lds) ? dpos[i] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 4 * k;
+                if (c >= nchunks) continue;
+                const int64_t i = (int64_t)c * 64 + lane;
+                if (a.stage_lds && i < m) {
+                    l_lam[i] = v[k];
+                    l_bidx[i] = bi[k];
+                    l_dpos[i] = dp[k];
+                }
+                const double cm = wave_min(v[k]);
+                if (lane == 0) chunkmin[c] = cm;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const RatioResult rr = a.stage_lds
+                                       ? ratio_fold(chunkmin, nchunks, m, l_lam, l_bidx, l_dpos, st->s_lambda0, a.eps, lane)
+                                       : ratio_fold(chunkmin, nchunks, m, lam, bidx, dpos, st->s_lambda0, a.eps, lane);
+            if (lane == 0) {
+                s_lambda = rr.lambda;
+                s_nb = rr.nb;
+                s_side = rr.side;
+            }
+        }
+        __syncthreads();
+        lambda = s_lambda;
+        r = s_nb;
+        side = s_side;
+        const bool leader = blockIdx.x == 0 && tid == 0;
+        if (st->nan_flag) {
+            if (leader) st->status = ELLP_ERR_NAN;
+            return;
+        }
+        if (!(lambda >= 0.0)) {  // primal…:402
+            if (leader) {
+                st->panic_code = 402;
+                st->status = ELLP_ERR_PANIC;
+            }
+            return;
+        }
+        if (isinf(lambda)) {  // primal…:404-406
+            if (leader) {
+                st->iters += 1;
+                st->status = ELLP_UNBOUNDED;
+            }
+            return;
+        }
+    } else {
+        r = st->s_r;
+    }
+
+    const int at_lower = st->s_at_lower;
+    double d_r = 0.0, alpha_r = 0.0;
+    if (r >= 0) {
+        d_r = a.d[r];
+        alpha_r = (MODE == 0 && at_lower) ? -d_r : d_r;
+        eta_update_rows(src, dst, m, a.ld, r, a.d, d_r, alpha_r, (int64_t)blockIdx.x * a.rows_per_block,
+                        a.rows_per_block, tid);
+    }
+    if (blockIdx.x != 0) return;
+
+    // ---------------- block 0: bookkeeping
+    const int64_t jq = st->s_jq;
+    if (MODE == 0) {
+        if (lambda > 0.0) {  // primal…:408-417
+            for (int64_t i0 = tid; i0 < m; i0 += 4 * 256) {
+                int64_t bi[4];
+                double xv[4], dv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t i = i0 + 256 * k;
+                    bi[k] = i < m ? a.B_index[i] : -1;
+                    dv[k] = i < m ? a.d[i] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k] = bi[k] >= 0 ? a.x[bi[k]] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bi[k] >= 0) a.x[bi[k]] = xv[k] + lambda * dv[k];
+            }
+            if (tid == 0) {
+                if (at_lower) a.x[jq] = a.x[jq] + lambda;
+                else a.x[jq] = a.x[jq] - lambda;
+            }
+        }
+        __syncthreads();  // B_index reads above vs the swap below
+        if (r >= 0) {
+            if (a.update_u) {
+                const double cf = st->s_rq / alpha_r;
+                const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
+                double2 *u2 = reinterpret_cast<double2 *>(a.u);
+                for (int64_t t = tid; t < (a.ld >> 1); t += 256) {
+                    const double2 p = rho2[t];
+                    double2 w = u2[t];
+                    w.x = fma(cf, p.x, w.x);
+                    w.y = fma(cf, p.y, w.y);
+                    u2[t] = w;
+                }
+            }
+            swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
+            if (tid == 0) {
+                const double tc = a.c_N[q];
+                a.c_N[q] = a.c_B[r];
+                a.c_B[r] = tc;
+                a.N_index[q] = a.B_index[r];
+                a.B_index[r] = jq;
+                a.Nb[q] = (uint8_t)side;
+                st->lambda = lambda;
+                st->cur = cur ^ 1;
+                st->pivots += 1;
+                st->iters += 1;
+            }
+        } else if (tid == 0) {  // primal…:223-231
+            const int nbq = a.Nb[q];
+            st->lambda = lambda;
+            if (nbq == ELLP_NB_LOWER) a.Nb[q] = ELLP_NB_UPPER;
+            else if (nbq == ELLP_NB_UPPER) a.Nb[q] = ELLP_NB_LOWER;
+            else {
+                st->panic_code = 229;  // "pivot should have been unbounded"
+                st->status = ELLP_ERR_PANIC;
+            }
+            st->flips += 1;
+            st->iters += 1;
+        }
+    } else {
+        // dual…:296-316
+        const double theta_d = st->s_theta_d, delta = st->s_delta;
+        const int64_t leaving_var = a.B_index[r];
+        const double theta_p = delta / d_r;
+        const double *rho = src + r * a.ld;
+        for (int64_t j0 = tid; j0 < a.nN; j0 += 4 * 256) {
+            int64_t v[4];
+            double al[4], dv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t j = j0 + 256 * k;
+                const bool ok = j < a.nN && j != q;
+                v[k] = ok ? a.N_index[j] : -1;
+                al[k] = ok ? a.alpha[j] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dv[k] = v[k] >= 0 ? a.dd[v[k]] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] >= 0) a.dd[v[k]] = dv[k] - theta_d * al[k];
+        }
+        for (int64_t i = tid; i < m; i += 256) {
+            a.y[i] = a.y[i] + theta_d * rho[i];
+            const int64_t bi = a.B_index[i];
+            a.x[bi] = a.x[bi] - theta_p * a.d[i];
+        }
+        __syncthreads();
+        swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
+        if (tid == 0) {
+            a.dd[leaving_var] = -theta_d;
+            a.dd[jq] = 0.0;
+            a.x[jq] = a.x[jq] + theta_p;
+            st->obj = st->obj + theta_d * delta;
+            a.B_index[r] = jq;  // dual…:322-333
+            a.N_index[q] = leaving_var;
+            a.Nb[q] = (uint8_t)st->s_side;
+            const double tc = a.c_N[q];
+            a.c_N[q] = a.c_B[r];
+            a.c_B[r] = tc;
+            st->cur = cur ^ 1;
+            st->pivots += 1;
+            st->iters += 1;
+            if (d_r != d_r || theta_p != theta_p) st->status = ELLP_ERR_NAN;
+        }
+        __syncthreads();
+        find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, m, tid, s_tmp, st);
+    }
+}
+
+// dual: leaving row before the first iteration of a run() slice
+struct DLeaveArgs {
+    const double *x, *lb, *ub;
+    const uint8_t *kind;
+    const int64_t *B_index;
+    DevState *st;
+    int64_t m;
+    double eps;
+};
+__global__ __launch_bounds__(256) void k_dleave(DLeaveArgs a) {
+    __shared__ long long s_tmp[4];
+    if (a.st->status != ST_RUNNING) return;
+    find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, a.m, threadIdx.x, s_tmp, a.st);
+}
+
 // ------------------------------------------------------------------ BTRAN  u = B^-T c_B  (primal…:184-187)
 // u_j = sum_i c_B[i] * W[i][j].  grid (col tiles of 512, row tiles): partial sums per row tile
 // then a fixed-order reduction — deterministic, no atomics.  Rows with c_B[i] == 0 are skipped
-// (phase 1: only artificial basics carry cost).
+// (phase 1: only artificial basics carry cost).  Runs every `btran_refresh` iterations; in
+// between u is carried by the O(m) update in k_update2.
 struct BtranArgs {
     const double *W0, *W1, *c_B;
     double *upart, *u;
@@ -760,17 +953,19 @@ __global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
 
 // ------------------------------------------------------------------ refactorisation of B^-1 from A_B
 // Product-form rebuild with partial pivoting: start from W = I and bring the m basic columns
-// in one at a time: alpha = W a_k (k_ftran mode 1), pivot row p = first max |alpha_i| over the
-// rows not used yet (the same pivot partial-pivot LU takes, primal…:173), eta update with row
-// p.  The pivot magnitudes are LU's U_kk, so the reference's singularity guard
-// (any |U_ii| < EPS, primal…:175-179) is checked on them.  Afterwards rows are permuted so that
-// row k belongs to basic position k.
+// in one at a time: alpha = W a_k, pivot row p = first max |alpha_i| over the rows not used yet
+// (the same pivot partial-pivot LU takes, primal…:173), eta update with row p.  The pivot
+// magnitudes are LU's U_kk, so the reference's singularity guard (any |U_ii| < EPS,
+// primal…:175-179) is checked on them.  Afterwards rows are permuted so that row k belongs to
+// basic position k.
 struct RefArgs {
     double *W0, *W1, *d;
+    const double *A_B;
     int32_t *used;
     int64_t *perm;
     DevState *st;
     int64_t m, ld;
+    int rows_per_block;
     double eps;
 };
 
@@ -783,7 +978,40 @@ __global__ __launch_bounds__(256) void k_ref_init(RefArgs a) {
         W[t] = (i == j) ? 1.0 : 0.0;
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.m; i += (int64_t)gridDim.x * 256) a.used[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.st->refk = 0;
+}
+__global__ void k_ref_begin(RefArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    a.st->refk = 0;
+}
+
+__global__ __launch_bounds__(256) void k_ref_ftran(RefArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int64_t half = a.ld >> 1;
+    const double *W = a.st->cur ? a.W1 : a.W0;
+    const double2 *col = reinterpret_cast<const double2 *>(a.A_B + a.st->refk * a.ld);
+    for (int64_t i = wave_global; i < a.m; i += nwaves) {
+        const double2 *row = reinterpret_cast<const double2 *>(W + i * a.ld);
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int64_t t0 = lane; t0 < half; t0 += 8 * WAVE) {
+            double2 w[8], c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t t = t0 + u * WAVE;
+                w[u] = t < half ? row[t] : make_double2(0.0, 0.0);
+                c[u] = t < half ? col[t] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc0 = fma(w[u].x, c[u].x, acc0);
+                acc1 = fma(w[u].y, c[u].y, acc1);
+            }
+        }
+        const double s = wave_sum(acc0 + acc1);
+        if (lane == 0) a.d[i] = s;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_ref_pick(RefArgs a) {
@@ -833,12 +1061,20 @@ __global__ __launch_bounds__(1024) void k_ref_pick(RefArgs a) {
             st->r = p;
             st->d_r = a.d[p];
             st->alpha_r = a.d[p];
-            st->swap_cols = 0;
-            st->cur ^= 1;
+            st->cur ^= 1;  // k_ref_update reads buffer cur^1, writes buffer cur
             st->do_update = 1;
             st->refk += 1;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_ref_update(RefArgs a) {
+    const DevState *st = a.st;
+    if (st->status != ST_RUNNING || !st->do_update) return;
+    const double *src = st->cur ? a.W0 : a.W1;
+    double *dst = st->cur ? a.W1 : a.W0;
+    eta_update_rows(src, dst, a.m, a.ld, st->r, a.d, st->d_r, st->alpha_r, (int64_t)blockIdx.x * a.rows_per_block,
+                    a.rows_per_block, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_ref_permute(RefArgs a) {
@@ -884,174 +1120,6 @@ __global__ __launch_bounds__(256) void k_inv_residual(const double *W0, const do
     if (threadIdx.x == 0) out[i] = fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]));
 }
 
-// ------------------------------------------------------------------ dual kernels
-// leaving row: FIRST basic position (in B order) whose variable violates a bound by more than
-// EPS (dual…:200-236) — a min-position reduction, exact as a tree.  rho = row r of B^-1
-// (dual…:248-253 obtains it by two triangular solves) is simply row r of the current buffer.
-struct DLeaveArgs {
-    const double *x, *lb, *ub;
-    const uint8_t *kind;
-    const int64_t *B_index;
-    DevState *st;
-    int64_t m;
-    double eps;
-};
-
-__device__ __forceinline__ bool dual_violation(const DLeaveArgs &a, int64_t i, double *delta, int *side) {
-    const int64_t bi = a.B_index[i];
-    const double xi = a.x[bi];
-    const int k = a.kind[bi];
-    if (k == ELLP_BOUND_LOWER) {
-        if (xi < a.lb[bi] - a.eps) { *delta = xi - a.lb[bi]; *side = ELLP_NB_LOWER; return true; }
-    } else if (k == ELLP_BOUND_UPPER) {
-        if (xi > a.ub[bi] + a.eps) { *delta = xi - a.ub[bi]; *side = ELLP_NB_UPPER; return true; }
-    } else if (k == ELLP_BOUND_TWOSIDED) {
-        if (xi > a.ub[bi] + a.eps) { *delta = xi - a.ub[bi]; *side = ELLP_NB_UPPER; return true; }
-        if (xi < a.lb[bi] - a.eps) { *delta = xi - a.lb[bi]; *side = ELLP_NB_LOWER; return true; }
-    }
-    return false;  // Free and Fixed basics never leave (quirk Q3)
-}
-
-__global__ __launch_bounds__(1024) void k_dleave(DLeaveArgs a) {
-    __shared__ long long s_i[16];
-    DevState *st = a.st;
-    if (st->status != ST_RUNNING) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long best = INT64_MAX;
-    double dl;
-    int sd;
-    for (int64_t i = tid; i < a.m; i += 1024) {
-        if (dual_violation(a, i, &dl, &sd)) {
-            best = i;
-            break;  // increasing i per thread: the first hit is this thread's minimum
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long ob = __shfl_xor(best, o);
-        best = ob < best ? ob : best;
-    }
-    if (lane == 0) s_i[wave] = best;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; ++w) best = s_i[w] < best ? s_i[w] : best;
-        if (best == INT64_MAX) {
-            st->iters += 1;
-            st->status = ELLP_OPTIMAL;  // dual…:243-246
-        } else {
-            double delta = 0.0;
-            int side = 0;
-            dual_violation(a, best, &delta, &side);
-            st->r = best;
-            st->delta = delta;
-            st->side = side;
-            st->do_update = 0;
-        }
-    }
-}
-
-// dual ratio argmin over the per-block minima (dual…:279: min_by keeps the FIRST minimum)
-struct DSelectArgs {
-    const double *blockkey;
-    const int64_t *blockpos;
-    DevState *st;
-    int nblocks;
-};
-__global__ __launch_bounds__(64) void k_dselect(DSelectArgs a) {
-    DevState *st = a.st;
-    if (st->status != ST_RUNNING) return;
-    const int lane = threadIdx.x;
-    if (st->nan_flag) {
-        if (lane == 0) st->status = ELLP_ERR_NAN;
-        return;
-    }
-    double bk = INFINITY;
-    long long bp = -1;
-    for (int b = lane; b < a.nblocks; b += WAVE) {
-        const long long p = a.blockpos[b];
-        if (p < 0) continue;
-        const double k = a.blockkey[b];
-        if (bp < 0 || k < bk || (k == bk && p < bp)) {
-            bk = k;
-            bp = p;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ok = __shfl_xor(bk, o);
-        const long long op = __shfl_xor(bp, o);
-        if (op >= 0 && (bp < 0 || ok < bk || (ok == bk && op < bp))) {
-            bk = ok;
-            bp = op;
-        }
-    }
-    if (lane == 0) {
-        if (bp < 0) {
-            st->iters += 1;
-            st->status = ELLP_INFEASIBLE;  // dual unbounded, dual…:281-284
-        } else {
-            st->q = bp;
-            st->at_lower = 0;
-            st->theta_d = (st->delta < 0.0) ? -bk : bk;  // dual…:286-289
-        }
-    }
-}
-
-// d, y, x updates and the index swap (dual…:296-333); arms the eta update.
-struct DUpdateArgs {
-    const double *W0, *W1;
-    double *c_B, *c_N, *x, *y, *dd;
-    const double *alpha, *alpha_q;
-    int64_t *B_index, *N_index;
-    uint8_t *Nb;
-    DevState *st;
-    int64_t m, ld, nN;
-};
-__global__ __launch_bounds__(1024) void k_dupdate(DUpdateArgs a) {
-    DevState *st = a.st;
-    if (st->status != ST_RUNNING) return;
-    const int tid = threadIdx.x;
-    const int64_t q = st->q, r = st->r;
-    const double theta_d = st->theta_d, delta = st->delta;
-    const int64_t leaving_var = a.B_index[r];
-    const int64_t entering_var = a.N_index[q];
-    const double aqr = a.alpha_q[r];
-    const double theta_p = delta / aqr;
-    const double *rho = (st->cur ? a.W1 : a.W0) + r * a.ld;
-    for (int64_t j = tid; j < a.nN; j += 1024) {
-        if (j == q) continue;
-        const int64_t v = a.N_index[j];
-        a.dd[v] = a.dd[v] - theta_d * a.alpha[j];
-    }
-    for (int64_t i = tid; i < a.m; i += 1024) {
-        a.y[i] = a.y[i] + theta_d * rho[i];
-        const int64_t bi = a.B_index[i];
-        a.x[bi] = a.x[bi] - theta_p * a.alpha_q[i];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        a.dd[leaving_var] = -theta_d;
-        a.dd[entering_var] = 0.0;
-        a.x[entering_var] = a.x[entering_var] + theta_p;
-        st->obj = st->obj + theta_d * delta;
-        st->theta_p = theta_p;
-        a.B_index[r] = entering_var;
-        a.N_index[q] = leaving_var;
-        a.Nb[q] = (uint8_t)st->side;
-        const double tc = a.c_N[q];
-        a.c_N[q] = a.c_B[r];
-        a.c_B[r] = tc;
-        st->d_r = aqr;
-        st->alpha_r = aqr;
-        st->swap_cols = 1;
-        st->cur ^= 1;
-        st->do_update = 1;
-        st->pivots += 1;
-        st->iters += 1;
-        if (aqr != aqr || theta_p != theta_p) st->status = ELLP_ERR_NAN;
-    }
-}
-
 // gather columns of A (m x n, ld m) into a padded destination (ld) by an index list
 __global__ __launch_bounds__(256) void k_gather_cols(const double *A, int64_t m, const int64_t *index, double *dst,
                                                      int64_t ld) {
@@ -1080,21 +1148,19 @@ struct ellp_engine {
     double *A_B = nullptr, *A_N = nullptr, *W = nullptr, *W2 = nullptr;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *r = nullptr, *key = nullptr;
     double *blockkey = nullptr, *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
-    double *upart = nullptr, *y = nullptr, *dd = nullptr, *g_lam = nullptr, *resid = nullptr;
+    double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr;
     int64_t *blockpos = nullptr, *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
-    uint8_t *kindv = nullptr, *Nb = nullptr, *g_dpos = nullptr;
-    int32_t *used = nullptr, *g_bidx = nullptr;
+    uint8_t *kindv = nullptr, *Nb = nullptr, *dpos = nullptr;
+    int32_t *used = nullptr, *bidx = nullptr;
     DevState *st = nullptr;
     DevState *h_st = nullptr;  // pinned
     // launch geometry
     int cpb = 1, nblocks = 1, priceT = 1;
-    int upd_rows = 2, upd_blocks = 1;
+    int upd_rows = 4, upd_blocks = 1;
     int ftran_blocks = 1;
     int btran_tiles = 1, btran_rows = 1;
-    int ratio_use_lds = 1;
-    size_t ratio_lds = 0;
-    int select_stage = 0;
-    size_t select_lds = 0;
+    int upd_stage = 1;
+    size_t upd_lds = 0, ftran_lds = 0;
     // loop bookkeeping
     uint64_t since_refactor = 0, since_btran = 0;
     int refactor_period = 0;
@@ -1214,14 +1280,27 @@ void launch_price(ellp_engine *e) {
     }
 }
 
-void launch_ftran(ellp_engine *e, int mode) {
-    FtranArgs a{e->W, e->W2, e->A_N, e->A_B, e->d, e->st, e->m, e->ld, mode};
-    hipLaunchKernelGGL(k_ftran, dim3(e->ftran_blocks), dim3(256), 0, e->stream, a);
+template <int MODE>
+void launch_ftran2(ellp_engine *e) {
+    Ftran2Args a{};
+    a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N;
+    a.key = e->key; a.blockkey = e->blockkey; a.r = e->r; a.blockpos = e->blockpos;
+    a.N_index = e->N_index; a.B_index = e->B_index; a.Nb = e->Nb; a.kind = e->kindv;
+    a.x = e->x; a.lb = e->lb; a.ub = e->ub;
+    a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos;
+    a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.cpb = e->cpb; a.eps = e->eps;
+    hipLaunchKernelGGL(k_ftran2<MODE>, dim3(e->ftran_blocks), dim3(256), e->ftran_lds, e->stream, a);
 }
 
-void launch_update(ellp_engine *e, int update_u) {
-    UpdateArgs a{e->W, e->W2, e->d, e->u, e->A_N, e->A_B, e->st, e->m, e->ld, e->upd_rows, update_u};
-    hipLaunchKernelGGL(k_update, dim3(e->upd_blocks), dim3(256), 0, e->stream, a);
+template <int MODE>
+void launch_update2(ellp_engine *e, int update_u) {
+    Update2Args a{};
+    a.W0 = e->W; a.W1 = e->W2; a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos; a.alpha = e->r;
+    a.u = e->u; a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+    a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+    a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd_rows; a.update_u = update_u;
+    a.stage_lds = e->upd_stage; a.eps = e->eps;
+    hipLaunchKernelGGL(k_update2<MODE>, dim3(e->upd_blocks), dim3(256), MODE == 0 ? e->upd_lds : 0, e->stream, a);
 }
 
 void launch_btran(ellp_engine *e) {
@@ -1234,12 +1313,13 @@ void launch_btran(ellp_engine *e) {
 
 void launch_refactor(ellp_engine *e) {
     Prof p(e, ELLP_K_REFACTOR);
-    RefArgs a{e->W, e->W2, e->d, e->used, e->perm, e->st, e->m, e->ld, e->eps};
+    RefArgs a{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows, e->eps};
+    hipLaunchKernelGGL(k_ref_begin, dim3(1), dim3(1), 0, e->stream, a);
     hipLaunchKernelGGL(k_ref_init, dim3(1024), dim3(256), 0, e->stream, a);
     for (int64_t k = 0; k < e->m; ++k) {
-        launch_ftran(e, 1);
+        hipLaunchKernelGGL(k_ref_ftran, dim3(e->ftran_blocks), dim3(256), 0, e->stream, a);
         hipLaunchKernelGGL(k_ref_pick, dim3(1), dim3(1024), 0, e->stream, a);
-        launch_update(e, 0);
+        hipLaunchKernelGGL(k_ref_update, dim3(e->upd_blocks), dim3(256), 0, e->stream, a);
     }
     hipLaunchKernelGGL(k_ref_permute, dim3((unsigned)e->m), dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, e->stream, a);
@@ -1261,30 +1341,12 @@ void launch_primal_iteration(ellp_engine *e) {
         launch_price<0>(e);
     }
     {
-        Prof p(e, ELLP_K_SELECT);
-        SelectArgs a{e->key, e->blockkey, e->r, e->N_index, e->Nb, e->st, e->nN, e->nblocks, e->cpb,
-                     e->select_stage, e->eps};
-        hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), e->select_lds, e->stream, a);
-    }
-    {
         Prof p(e, ELLP_K_FTRAN);
-        launch_ftran(e, 0);
-    }
-    {
-        Prof p(e, ELLP_K_RATIO);
-        RatioArgs a{};
-        a.c_B = e->c_B; a.c_N = e->c_N;
-        a.x = e->x; a.d = e->d; a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv;
-        a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
-        a.g_lam = e->g_lam; a.g_bidx = e->g_bidx; a.g_dpos = e->g_dpos;
-        a.st = e->st; a.m = e->m; a.use_lds = e->ratio_use_lds; a.eps = e->eps;
-        if (e->m <= 2048) hipLaunchKernelGGL(k_ratio<2>, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
-        else if (e->m <= 4096) hipLaunchKernelGGL(k_ratio<4>, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
-        else hipLaunchKernelGGL(k_ratio<8>, dim3(1), dim3(1024), e->ratio_lds, e->stream, a);
+        launch_ftran2<0>(e);
     }
     {
         Prof p(e, ELLP_K_UPDATE);
-        launch_update(e, e->opts.btran_mode == 1 ? 0 : 1);
+        launch_update2<0>(e, e->opts.btran_mode == 1 ? 0 : 1);
     }
     e->since_btran += 1;
     e->since_refactor += 1;
@@ -1292,37 +1354,24 @@ void launch_primal_iteration(ellp_engine *e) {
 
 void launch_dual_iteration(ellp_engine *e) {
     {
-        Prof p(e, ELLP_K_DLEAVE);
-        DLeaveArgs a{e->x, e->lb, e->ub, e->kindv, e->B_index, e->st, e->m, e->eps};
-        hipLaunchKernelGGL(k_dleave, dim3(1), dim3(1024), 0, e->stream, a);
-    }
-    {
         Prof p(e, ELLP_K_DPRICE);
         launch_price<1>(e);
     }
     {
-        Prof p(e, ELLP_K_DSELECT);
-        DSelectArgs a{e->blockkey, e->blockpos, e->st, e->nblocks};
-        hipLaunchKernelGGL(k_dselect, dim3(1), dim3(64), 0, e->stream, a);
-    }
-    {
         Prof p(e, ELLP_K_FTRAN);
-        launch_ftran(e, 0);
+        launch_ftran2<1>(e);
     }
     {
         Prof p(e, ELLP_K_DUPDATE);
-        DUpdateArgs a{};
-        a.W0 = e->W; a.W1 = e->W2; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
-        a.alpha = e->r; a.alpha_q = e->d;
-        a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb; a.st = e->st;
-        a.m = e->m; a.ld = e->ld; a.nN = e->nN;
-        hipLaunchKernelGGL(k_dupdate, dim3(1), dim3(1024), 0, e->stream, a);
-    }
-    {
-        Prof p(e, ELLP_K_UPDATE);
-        launch_update(e, 0);
+        launch_update2<1>(e, 0);
     }
     e->since_refactor += 1;
+}
+
+void launch_dleave(ellp_engine *e) {
+    Prof p(e, ELLP_K_DLEAVE);
+    DLeaveArgs a{e->x, e->lb, e->ub, e->kindv, e->B_index, e->st, e->m, e->eps};
+    hipLaunchKernelGGL(k_dleave, dim3(1), dim3(256), 0, e->stream, a);
 }
 
 ellp_status status_message(const DevState &s, char *errbuf, size_t errlen) {
@@ -1503,24 +1552,16 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         if (e->btran_rows < 8) e->btran_rows = 8;
         e->btran_tiles = (int)((m + e->btran_rows - 1) / e->btran_rows);
         const int nchunks = (int)((m + 63) >> 6);
-        size_t lds = sizeof(double) * (size_t)nchunks + (size_t)m * (8 + 4 + 1) + 16;
-        if (lds <= 140 * 1024) {
-            e->ratio_use_lds = 1;
-            e->ratio_lds = lds;
+        const size_t staged = sizeof(double) * (size_t)nchunks + (size_t)m * (8 + 4 + 1) + 16;
+        if (staged <= 40 * 1024) {  // keep >= 4 update blocks per CU resident
+            e->upd_stage = 1;
+            e->upd_lds = staged;
         } else {
-            e->ratio_use_lds = 0;
-            e->ratio_lds = sizeof(double) * (size_t)nchunks + 16;
+            e->upd_stage = 0;
+            e->upd_lds = sizeof(double) * (size_t)nchunks + 16;
         }
+        e->ftran_lds = sizeof(double) * (size_t)e->nblocks + 16;
         e->refactor_period = e->opts.refactor_period > 0 ? e->opts.refactor_period : 0;
-        // entering selection: stage keys + indices in LDS when they fit (<= 140 KiB)
-        const size_t stage = sizeof(double) * (size_t)e->nblocks + (size_t)nNa * 12 + 16;
-        if (stage <= 140 * 1024) {
-            e->select_stage = 1;
-            e->select_lds = stage;
-        } else {
-            e->select_stage = 0;
-            e->select_lds = sizeof(double) * (size_t)e->nblocks + 16;
-        }
     }
 
     ECHK(dmalloc(e, &e->A_B, (size_t)(ld * m)));
@@ -1545,9 +1586,9 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->Nb, (size_t)nNa));
     ECHK(dmalloc(e, &e->perm, (size_t)m));
     ECHK(dmalloc(e, &e->used, (size_t)m));
-    ECHK(dmalloc(e, &e->g_lam, (size_t)m));
-    ECHK(dmalloc(e, &e->g_bidx, (size_t)m));
-    ECHK(dmalloc(e, &e->g_dpos, (size_t)m));
+    ECHK(dmalloc(e, &e->lam, (size_t)m));
+    ECHK(dmalloc(e, &e->bidx, (size_t)m));
+    ECHK(dmalloc(e, &e->dpos, (size_t)m));
     ECHK(dmalloc(e, &e->resid, (size_t)m));
     ECHK(dmalloc(e, &e->st, 1));
     ECHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_st), sizeof(DevState), hipHostMallocDefault));
@@ -1603,6 +1644,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         memset(&init, 0, sizeof(init));
         init.status = ST_RUNNING;
         init.r = -1;
+        init.lr = -1;
         if (kind == ELLP_ENGINE_DUAL) {
             UCHK(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)ld, e->stream));
             UCHK(hipMemcpyAsync(e->y, y, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, e->stream));
@@ -1615,18 +1657,6 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         (void)hipFree(A_full);
         (void)hipFree(c_full);
 #undef UCHK
-    }
-    if (e->ratio_lds > 48 * 1024) {
-        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)e->ratio_lds));
-        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)e->ratio_lds));
-        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ratio<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)e->ratio_lds));
-    }
-    if (e->select_lds > 48 * 1024) {
-        ECHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_select), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)e->select_lds));
     }
     // dual: initial dual feasibility assertion (dual…:139-151) — host side, data is in hand
     if (kind == ELLP_ENGINE_DUAL) {
@@ -1684,6 +1714,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
     } else {
         uint64_t remaining = max_iters;
+        if (e->kind == ELLP_ENGINE_DUAL && remaining > 0) launch_dleave(e);
         // a previous slice may already have terminated
         HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
