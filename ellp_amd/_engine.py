@@ -89,6 +89,17 @@ def lib():
     L.ellp_engine_inverse_residual.restype = C.c_double
     L.ellp_engine_inverse_residual.argtypes = [C.c_void_p]
     L.ellp_engine_destroy.argtypes = [C.c_void_p]
+    L.ellp_engine_set_shard.restype = C.c_int
+    L.ellp_engine_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.ellp_engine_exchange_info.restype = C.c_int
+    L.ellp_engine_exchange_info.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ellp_engine_set_stream.restype = C.c_int
+    L.ellp_engine_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.ellp_engine_step.restype = C.c_int
+    L.ellp_engine_step.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.ellp_engine_poll.restype = C.c_int
+    L.ellp_engine_poll.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -203,6 +214,35 @@ class Engine:
 
     def inverse_residual(self):
         return lib().ellp_engine_inverse_residual(self._h)
+
+    # ---- sharded / stepped driving (see ellp_amd/dist.py)
+    def set_shard(self, rank, world):
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_set_shard(self._h, int(rank), int(world), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def exchange_info(self):
+        base, seg, rank, world = C.c_void_p(), C.c_int64(), C.c_int(), C.c_int()
+        lib().ellp_engine_exchange_info(self._h, C.byref(base), C.byref(seg), C.byref(rank), C.byref(world))
+        return base.value, seg.value, rank.value, world.value
+
+    def set_stream(self, stream_handle):
+        lib().ellp_engine_set_stream(self._h, C.c_void_p(stream_handle))
+
+    def step(self, phase):
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_step(self._h, int(phase), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def poll(self):
+        st = Stats()
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_poll(self._h, C.byref(st), err, 512)
+        if s == ERR_DEVICE:
+            raise EllpHipError(s, err.value.decode())
+        return s, st, err.value.decode()
 
     def close(self):
         if self._h:

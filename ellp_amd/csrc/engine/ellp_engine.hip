@@ -90,6 +90,30 @@ __device__ __forceinline__ double wave_min(double v) {
     return v;
 }
 
+// ------------------------------------------------------------------ pricing output / exchange buffer
+// The pricing kernels write their per-column and per-block results into ONE buffer laid out in
+// `world` equal segments, one per rank (world = 1 on a single GPU):
+//   segment s = [ blockkey (nbs) | blockpos (nbs, stored as f64) | key (nbs*cpb) | r (nbs*cpb) ]
+// where rank s prices the blocks [s*nbs, (s+1)*nbs), i.e. nonbasic positions
+// [s*nbs*cpb, (s+1)*nbs*cpb).  With column-block sharding each rank fills its own
+// segment and ONE all-gather of the buffer per iteration gives every rank the complete
+// pricing result; everything downstream is replicated and deterministic.
+struct Xchg {
+    double *X;
+    int64_t seg;  // doubles per segment = 2*nbs + 2*nbs*cpb
+    int nbs, cpb;
+    __device__ __forceinline__ double &bk(int b) const { return X[(int64_t)(b / nbs) * seg + (b % nbs)]; }
+    __device__ __forceinline__ double &bp(int b) const { return X[(int64_t)(b / nbs) * seg + nbs + (b % nbs)]; }
+    __device__ __forceinline__ double &key(int64_t j) const {
+        const int64_t per = (int64_t)nbs * cpb, s = j / per;
+        return X[s * seg + 2 * nbs + (j - s * per)];
+    }
+    __device__ __forceinline__ double &r(int64_t j) const {
+        const int64_t per = (int64_t)nbs * cpb, s = j / per;
+        return X[s * seg + 2 * nbs + per + (j - s * per)];
+    }
+};
+
 // ------------------------------------------------------------------ pricing
 // MODE 0 (primal): r_j = c_N[j] - A_N[:,j].u for every nonbasic column (primal…:189), fused with
 // the eligibility filter / Dantzig key of pivot() (primal…:253-270) and a per-block key maximum.
@@ -109,13 +133,11 @@ struct PriceArgs {
     const uint8_t *Nb;
     const int64_t *N_index;
     const double *dd;       // dual: reduced costs d (indexed by variable)
-    double *r;              // primal: r ; dual: alpha
-    double *key;            // primal: Dantzig key (or -inf)
-    double *blockkey;       // per-block max (primal) / min (dual)
-    int64_t *blockpos;      // dual: position of the block's first minimum
+    Xchg xc;                // out: r / alpha, key, per-block max (primal) or first argmin (dual)
     DevState *st;
     int64_t ld, nN;
     int cpb;
+    int block0;             // first pricing block of this rank
     double eps;
 };
 
@@ -150,7 +172,8 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
         const int64_t idx = tid + 256 * t;
         ur[t] = idx < half ? u2[idx] : make_double2(0.0, 0.0);
     }
-    const int64_t j0 = (int64_t)blockIdx.x * a.cpb;
+    const int gb = a.block0 + (int)blockIdx.x;  // global pricing block
+    const int64_t j0 = (int64_t)gb * a.cpb;
     const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
     double best = (MODE == 0) ? -INFINITY : INFINITY;
     long long bestpos = -1;
@@ -202,11 +225,11 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
                     else if (!pos && nb == ELLP_NB_LOWER) key = -rj;
                     else if (nb == ELLP_NB_FREE) key = fabs(rj);
                 }
-                a.r[jj] = rj;
-                a.key[jj] = key;
+                a.xc.r(jj) = rj;
+                a.xc.key(jj) = key;
                 best = fmax(best, key);
             } else {
-                a.r[jj] = dot;  // alpha (un-negated, dual…:286-288 restores the sign anyway)
+                a.xc.r(jj) = dot;  // alpha (un-negated, dual…:286-288 restores the sign anyway)
                 const double al = sgn * dot;
                 bool keep;
                 if (nb == ELLP_NB_LOWER) keep = al > a.eps;
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
             double v = (lane < 4) ? best : -INFINITY;
             v = fmax(v, __shfl_xor(v, 1));
             v = fmax(v, __shfl_xor(v, 2));
-            if (lane == 0) a.blockkey[blockIdx.x] = v;
+            if (lane == 0) a.xc.bk(gb) = v;
         }
     } else {
         if (tid < 4) {
@@ -247,8 +270,8 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
                     bp = s_p[k];
                 }
             }
-            a.blockkey[blockIdx.x] = bk;
-            a.blockpos[blockIdx.x] = bp;
+            a.xc.bk(gb) = bk;
+            a.xc.bp(gb) = (double)bp;
         }
     }
 }
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
 // cannot change the accumulator: a block whose maximum key is <= acc - EPS holds no such
 // element.  Work is O(#blocks/64 + #accumulator changes).  s_bk = block maxima staged in LDS.
 __device__ __forceinline__ long long entering_fold(const double *s_bk, int nblocks, int cpb, int64_t nN,
-                                                   const double *key, const int64_t *N_index, double eps,
+                                                   const Xchg &xc, const int64_t *N_index, double eps,
                                                    int lane) {
     bool have = false;
     double racc = 0.0;
@@ -277,7 +300,7 @@ __device__ __forceinline__ long long entering_fold(const double *s_bk, int nbloc
             const int64_t jb = (int64_t)(g0 + bl) * cpb;
             const int64_t j = jb + lane;
             const bool valid = lane < cpb && j < nN;
-            const double k = valid ? key[j] : -INFINITY;
+            const double k = valid ? xc.key(j) : -INFINITY;
             const long long idx = valid ? N_index[j] : 0;
             int efrom = 0;
             for (;;) {
@@ -310,8 +333,7 @@ __device__ __forceinline__ long long entering_fold(const double *s_bk, int nbloc
 // by bound kind (primal…:320-367) so that k_update2's fold only reads three flat arrays.
 struct Ftran2Args {
     const double *W0, *W1, *A_N;
-    const double *key, *blockkey, *r;
-    const int64_t *blockpos;
+    Xchg xc;
     const int64_t *N_index, *B_index;
     const uint8_t *Nb, *kind;
     const double *x, *lb, *ub;
@@ -341,14 +363,14 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         for (int b0 = tid; b0 < a.nblocks; b0 += 4 * 256) {
             double v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (b0 + 256 * u < a.nblocks) ? a.blockkey[b0 + 256 * u] : 0.0;
+            for (int u = 0; u < 4; ++u) v[u] = (b0 + 256 * u < a.nblocks) ? a.xc.bk(b0 + 256 * u) : 0.0;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (b0 + 256 * u < a.nblocks) s_bk[b0 + 256 * u] = v[u];
         }
         __syncthreads();
         if (wave == 0) {
-            const long long q = entering_fold(s_bk, a.nblocks, a.cpb, a.nN, a.key, a.N_index, a.eps, lane);
+            const long long q = entering_fold(s_bk, a.nblocks, a.cpb, a.nN, a.xc, a.N_index, a.eps, lane);
             if (lane == 0) s_q = q;
         }
         __syncthreads();
@@ -357,9 +379,9 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         double bk = INFINITY;
         long long bp = -1;
         for (int b = tid; b < a.nblocks; b += 256) {
-            const long long p = a.blockpos[b];
+            const long long p = (long long)a.xc.bp(b);
             if (p < 0) continue;
-            const double k = a.blockkey[b];
+            const double k = a.xc.bk(b);
             if (bp < 0 || k < bk || (k == bk && p < bp)) {
                 bk = k;
                 bp = p;
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         if (MODE == 0) {
             const int64_t jq = a.N_index[q];
             st->s_jq = jq;
-            st->s_rq = a.r[q];
+            st->s_rq = a.xc.r(q);
             const int k = a.kind[jq];  // primal…:305-311
             st->s_lambda0 = (k == ELLP_BOUND_TWOSIDED) ? a.ub[jq] - a.lb[jq] : (k == ELLP_BOUND_FIXED ? 0.0 : INFINITY);
         } else {
@@ -657,7 +679,7 @@ struct Update2Args {
     const double *lam;
     const int32_t *bidx;
     const uint8_t *dpos;
-    const double *alpha;  // dual: alpha (per nonbasic position)
+    Xchg xc;              // dual: alpha_j = xc.r(j)
     double *u, *A_N, *A_B, *c_B, *c_N, *x, *y, *dd;
     const double *lb, *ub;
     const uint8_t *kind;
@@ -850,7 +872,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 const int64_t j = j0 + 256 * k;
                 const bool ok = j < a.nN && j != q;
                 v[k] = ok ? a.N_index[j] : -1;
-                al[k] = ok ? a.alpha[j] : 0.0;
+                al[k] = ok ? a.xc.r(j) : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) dv[k] = v[k] >= 0 ? a.dd[v[k]] : 0.0;
@@ -1146,14 +1168,19 @@ struct ellp_engine {
     hipStream_t stream = nullptr;
     // device memory
     double *A_B = nullptr, *A_N = nullptr, *W = nullptr, *W2 = nullptr;
-    double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *r = nullptr, *key = nullptr;
-    double *blockkey = nullptr, *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
+    double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
+    double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr;
-    int64_t *blockpos = nullptr, *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
+    int64_t *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
     uint8_t *kindv = nullptr, *Nb = nullptr, *dpos = nullptr;
     int32_t *used = nullptr, *bidx = nullptr;
     DevState *st = nullptr;
     DevState *h_st = nullptr;  // pinned
+    // pricing shard (column-block sharding across ranks; world = 1 on a single GPU)
+    int rank = 0, world = 1, nbs = 1;
+    int64_t seg = 0;
+    hipStream_t own_stream = nullptr;
+    bool need_dleave = true;
     // launch geometry
     int cpb = 1, nblocks = 1, priceT = 1;
     int upd_rows = 4, upd_blocks = 1;
@@ -1261,16 +1288,17 @@ void launch_price(ellp_engine *e) {
     a.Nb = e->Nb;
     a.N_index = e->N_index;
     a.dd = e->dd;
-    a.r = e->r;
-    a.key = e->key;
-    a.blockkey = e->blockkey;
-    a.blockpos = e->blockpos;
+    a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
     a.st = e->st;
     a.ld = e->ld;
     a.nN = e->nN;
     a.cpb = e->cpb;
+    a.block0 = e->rank * e->nbs;
     a.eps = e->eps;
-    dim3 g(e->nblocks), b(256);
+    int mine = e->nblocks - a.block0;
+    if (mine > e->nbs) mine = e->nbs;
+    if (mine <= 0) return;  // this rank's shard is empty (more ranks than pricing blocks)
+    dim3 g(mine), b(256);
     switch (e->priceT) {
     case 1: hipLaunchKernelGGL((k_price<1, MODE>), g, b, 0, e->stream, a); break;
     case 2: hipLaunchKernelGGL((k_price<2, MODE>), g, b, 0, e->stream, a); break;
@@ -1284,7 +1312,7 @@ template <int MODE>
 void launch_ftran2(ellp_engine *e) {
     Ftran2Args a{};
     a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N;
-    a.key = e->key; a.blockkey = e->blockkey; a.r = e->r; a.blockpos = e->blockpos;
+    a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
     a.N_index = e->N_index; a.B_index = e->B_index; a.Nb = e->Nb; a.kind = e->kindv;
     a.x = e->x; a.lb = e->lb; a.ub = e->ub;
     a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos;
@@ -1295,7 +1323,7 @@ void launch_ftran2(ellp_engine *e) {
 template <int MODE>
 void launch_update2(ellp_engine *e, int update_u) {
     Update2Args a{};
-    a.W0 = e->W; a.W1 = e->W2; a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos; a.alpha = e->r;
+    a.W0 = e->W; a.W1 = e->W2; a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
     a.u = e->u; a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd_rows; a.update_u = update_u;
@@ -1429,6 +1457,7 @@ void ellp_engine_destroy(ellp_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->stream = e->own_stream;
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_st) (void)hipHostFree(e->h_st);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -1528,6 +1557,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
 
     ECHK(hipSetDevice(dev));
     ECHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = e->stream;
     const int64_t ld = e->ld;
     const int64_t nNa = n_N > 0 ? n_N : 1;
     // geometry
@@ -1571,10 +1601,9 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->c_B, (size_t)m));
     ECHK(dmalloc(e, &e->c_N, (size_t)nNa));
     ECHK(dmalloc(e, &e->u, (size_t)ld));
-    ECHK(dmalloc(e, &e->r, (size_t)nNa));
-    ECHK(dmalloc(e, &e->key, (size_t)nNa));
-    ECHK(dmalloc(e, &e->blockkey, (size_t)e->nblocks));
-    ECHK(dmalloc(e, &e->blockpos, (size_t)e->nblocks));
+    e->nbs = e->nblocks;
+    e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
+    ECHK(dmalloc(e, &e->X, (size_t)e->seg));
     ECHK(dmalloc(e, &e->x, (size_t)n_c));
     ECHK(dmalloc(e, &e->lb, (size_t)n_c));
     ECHK(dmalloc(e, &e->ub, (size_t)n_c));
@@ -1714,7 +1743,14 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
     } else {
         uint64_t remaining = max_iters;
-        if (e->kind == ELLP_ENGINE_DUAL && remaining > 0) launch_dleave(e);
+        if (e->world != 1) {
+            set_err(errbuf, errlen, "a sharded engine is driven with ellp_engine_step + an all-gather (ellp_amd/dist.py)");
+            return ELLP_ERR_ARG;
+        }
+        if (e->kind == ELLP_ENGINE_DUAL && remaining > 0 && e->need_dleave) {
+            launch_dleave(e);
+            e->need_dleave = false;
+        }
         // a previous slice may already have terminated
         HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -1780,10 +1816,18 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
     int64_t count = 0;
     switch (what) {
     case ELLP_TAP_U: src = e->u; count = e->m; break;
-    case ELLP_TAP_R: src = e->r; count = e->nN; break;
-    case ELLP_TAP_ALPHA: src = e->r; count = e->nN; break;
+    case ELLP_TAP_R:
+    case ELLP_TAP_ALPHA:
+        if (e->world != 1) return ELLP_ERR_ARG;
+        src = e->X + 2 * e->nbs + (int64_t)e->nbs * e->cpb;
+        count = e->nN;
+        break;
     case ELLP_TAP_D: src = e->d; count = e->m; break;
-    case ELLP_TAP_KEY: src = e->key; count = e->nN; break;
+    case ELLP_TAP_KEY:
+        if (e->world != 1) return ELLP_ERR_ARG;
+        src = e->X + 2 * e->nbs;
+        count = e->nN;
+        break;
     case ELLP_TAP_BINV: {
         // row-major m x m without the padding
         count = e->m * e->m;
@@ -1820,6 +1864,113 @@ double ellp_engine_inverse_residual(ellp_engine *e) {
     double w = 0.0;
     for (double v : h) w = (v > w || v != v) ? v : w;
     return w;
+}
+
+ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, char *errbuf, size_t errlen) {
+    if (!e || world < 1 || rank < 0 || rank >= world) {
+        set_err(errbuf, errlen, "bad rank/world");
+        return ELLP_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->rank = rank;
+    e->world = world;
+    e->nbs = (e->nblocks + world - 1) / world;
+    e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
+    double *nx = nullptr;
+    HIPCHK(dmalloc(e, &nx, (size_t)(e->seg * world)));
+    HIPCHK(hipMemset(nx, 0, sizeof(double) * (size_t)(e->seg * world)));
+    e->X = nx;  // the previous buffer stays in e->allocs and is released with the engine
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_doubles, int *rank, int *world) {
+    if (!e) return ELLP_ERR_ARG;
+    if (base) *base = e->X;
+    if (seg_doubles) *seg_doubles = e->seg;
+    if (rank) *rank = e->rank;
+    if (world) *world = e->world;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream) {
+    if (!e) return ELLP_ERR_ARG;
+    if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    (void)hipStreamSynchronize(e->stream);
+    e->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : e->own_stream;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t errlen) {
+    if (!e) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    if (e->nN == 0) return ELLP_OPTIMAL;
+    if (phase == 0) {
+        int64_t period = e->refactor_period > 0 ? e->refactor_period : 100;
+        if (e->since_refactor >= (uint64_t)period) launch_refactor(e);
+        if (e->kind == ELLP_ENGINE_PRIMAL) {
+            const bool full_btran =
+                (e->opts.btran_mode == 1) || !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;
+            if (full_btran) {
+                Prof p(e, ELLP_K_BTRAN);
+                launch_btran(e);
+                e->since_btran = 0;
+                e->u_valid = true;
+            }
+            Prof p(e, ELLP_K_PRICE);
+            launch_price<0>(e);
+        } else {
+            if (e->need_dleave) {
+                launch_dleave(e);
+                e->need_dleave = false;
+            }
+            Prof p(e, ELLP_K_DPRICE);
+            launch_price<1>(e);
+        }
+    } else {
+        if (e->kind == ELLP_ENGINE_PRIMAL) {
+            {
+                Prof p(e, ELLP_K_FTRAN);
+                launch_ftran2<0>(e);
+            }
+            Prof p(e, ELLP_K_UPDATE);
+            launch_update2<0>(e, e->opts.btran_mode == 1 ? 0 : 1);
+            e->since_btran += 1;
+        } else {
+            {
+                Prof p(e, ELLP_K_FTRAN);
+                launch_ftran2<1>(e);
+            }
+            Prof p(e, ELLP_K_DUPDATE);
+            launch_update2<1>(e, 0);
+        }
+        e->since_refactor += 1;
+    }
+    HIPCHK(hipGetLastError());
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, size_t errlen) {
+    if (!e) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->iters = e->h_st->iters;
+        stats->pivots = e->h_st->pivots;
+        stats->bound_flips = e->h_st->flips;
+        stats->refactors = e->refactors;
+        stats->obj = e->h_st->obj;
+        stats->t_setup_s = e->t_setup;
+        for (int k = 0; k < ELLP_K_COUNT; ++k) {
+            stats->kernel_ms[k] = e->kernel_ms[k];
+            stats->kernel_calls[k] = e->kernel_calls[k];
+        }
+    }
+    if (e->h_st->status == ST_RUNNING) return ELLP_MAXITER;  // still running: the slice is simply used up
+    return status_message(*e->h_st, errbuf, errlen);
 }
 
 static ellp_status solve_once(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,

@@ -1,0 +1,103 @@
+"""Column-block pricing sharded over several GPUs, one process per GPU.
+
+The nonbasic positions are cut into `world` contiguous blocks.  Per simplex iteration every
+rank prices its own block (k_price), then ONE all-gather of the engine's exchange buffer
+(per-block maxima/argmins, Dantzig keys, reduced costs; `seg` doubles per rank) gives every
+rank the complete pricing result, and the rest of the iteration (entering fold, FTRAN, ratio
+test, eta update of B^-1, bookkeeping) runs replicated and deterministically on every rank, so
+all ranks take the same pivots and hold the same point.  The collective is
+`torch.distributed.all_gather_into_tensor` — RCCL over xGMI with backend "nccl"; with backend
+"gloo" (tests) the segments are staged through host memory.
+"""
+import time
+
+import numpy as np
+
+from . import _engine as E
+
+
+class _DevBuf:
+    """A raw device pointer dressed up for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def shard_ranges(n_positions, cpb, world):
+    """[(first, last+1)] nonbasic positions priced by each rank (mirrors ellp_engine_set_shard)."""
+    nblocks = (max(n_positions, 1) + cpb - 1) // cpb
+    nbs = (nblocks + world - 1) // world
+    out = []
+    for r in range(world):
+        a = min(n_positions, r * nbs * cpb)
+        b = min(n_positions, (r + 1) * nbs * cpb)
+        out.append((a, b))
+    return out
+
+
+def all_gather_segments(full, mine, rank, world, group=None):
+    """All-gather `mine` (this rank's segment) into `full` (world * seg).  Works for device
+    tensors with the nccl backend and for CPU tensors (or device tensors staged through the
+    host) with gloo."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        dist.all_gather_into_tensor(full, mine, group=group)
+        return
+    src = mine.detach().cpu().contiguous()
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    full.copy_(torch.cat(parts).to(full.device))
+
+
+class ShardedEngine:
+    """Drives one `Engine` per rank with the pricing pass sharded over the process group."""
+
+    def __init__(self, kind, fp, opts=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        self.eng = E.Engine(kind, fp, opts)
+        self.eng.set_shard(self.rank, self.world)
+        base, seg, _, _ = self.eng.exchange_info()
+        self.seg = seg
+        self.full = torch.as_tensor(_DevBuf(base, seg * self.world), device="cuda")
+        self.send = torch.empty(seg, dtype=torch.float64, device="cuda")
+        # the engine's launches and the collective must be ordered: share torch's current stream
+        self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def exchange(self):
+        if self.world == 1:
+            return
+        self.send.copy_(self.full[self.rank * self.seg:(self.rank + 1) * self.seg])
+        all_gather_segments(self.full, self.send, self.rank, self.world, self.group)
+
+    def run(self, max_iters, poll_interval=16):
+        """Up to `max_iters` further iterations; returns (status, Stats, message) like Engine.run."""
+        done = 0
+        status, stats, msg = self.eng.poll()
+        while status == E.MAXITER and done < max_iters:
+            batch = min(poll_interval, max_iters - done)
+            for _ in range(batch):
+                self.eng.step(0)
+                self.exchange()
+                self.eng.step(1)
+            done += batch
+            status, stats, msg = self.eng.poll()
+        return status, stats, msg
+
+    def read_point(self):
+        return self.eng.read_point()
+
+    def close(self):
+        self.torch.cuda.current_stream().synchronize()
+        self.eng.set_stream(None)
+        self.eng.close()

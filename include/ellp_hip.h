@@ -161,6 +161,26 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index,
                                    int64_t *N_index, uint8_t *N_bound, double *y, double *d,
                                    char *errbuf, size_t errbuf_len);
 
+/*
+ * Column-block sharding of the pricing pass over several GPUs (one process per GPU).
+ * The nonbasic positions are split into `world` contiguous blocks; rank k prices block k and
+ * writes (per-block maxima / argmins, keys, reduced costs) into segment k of one exchange
+ * buffer of world*seg doubles.  Between ellp_engine_step(e, 0) [pricing] and
+ * ellp_engine_step(e, 1) [FTRAN + ratio test + eta update] the caller all-gathers that buffer
+ * (RCCL over xGMI via torch.distributed, see ellp_amd/dist.py); everything else is replicated on
+ * every rank and deterministic, so all ranks take the same pivots.
+ *   set_shard   : choose (rank, world) before the first step; re-allocates the exchange buffer
+ *   exchange_info: device pointer of the buffer, doubles per segment, rank, world
+ *   set_stream  : run the engine's launches on a caller-owned HIP stream (NULL = its own)
+ *   step        : enqueue one half-iteration (never blocks)
+ *   poll        : copy the status word back; ELLP_MAXITER = still running
+ */
+ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, char *errbuf, size_t errbuf_len);
+ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_doubles, int *rank, int *world);
+ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream);
+ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t errbuf_len);
+ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, size_t errbuf_len);
+
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
 enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,

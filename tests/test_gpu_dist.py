@@ -1,0 +1,108 @@
+"""N>1 path on the GPU box: two processes (both on GPU 0, gloo exchange staged through the
+host) drive sharded engines with the stepped API; every rank must take exactly the pivots of the
+unsharded engine (same iteration count, basis and point), for primal and dual."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _flat(seed, m, n):
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(seed, m, n)
+    return E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                         f["x"], f["B"], f["N"], f["Nb"])
+
+
+def _dual_flat():
+    """dual phase-1 arrays of a small synthetic LP, built by the oracle's setup (test input)."""
+    from ellp_amd import _engine as E
+    from oracle import ellp_oracle as eo
+    p1, err = eo.dual_phase1(eo.synth_problem(20260301, 20, 50))
+    v = p1.view()
+    return E.FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B, v.N[:v.nN],
+                         v.Nb[:v.nN], v.y, v.d)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ellp_amd import _engine as E
+        from ellp_amd.dist import ShardedEngine
+        out = {}
+        for name, kind, make in (("primal", E.ENGINE_PRIMAL, lambda: _flat(20260301, 50, 120)),
+                                 ("dual", E.ENGINE_DUAL, _dual_flat)):
+            opts = E.default_opts(max_iter=None, device=0)
+            ref_fp = make()
+            ref = E.Engine(kind, ref_fp, opts)
+            st_ref, stats_ref, _ = ref.run(100000)
+            ref.read_point()
+            ref.close()
+            fp = make()
+            sh = ShardedEngine(kind, fp, opts)
+            st, stats, msg = sh.run(100000, poll_interval=8)
+            sh.read_point()
+            sh.close()
+            out[name] = dict(
+                same_status=(st == st_ref), status=int(st), iters=int(stats.iters), iters_ref=int(stats_ref.iters),
+                same_B=bool(np.array_equal(fp.B, ref_fp.B)), same_N=bool(np.array_equal(fp.N, ref_fp.N)),
+                same_x=bool(np.array_equal(fp.x, ref_fp.x)), msg=msg)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_engine_takes_the_same_pivots_world2():
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in results:
+        for name, r in out.items():
+            assert r["same_status"] and r["status"] == 0, (rank, name, r)
+            assert r["iters"] == r["iters_ref"] > 0, (rank, name, r)
+            assert r["same_B"] and r["same_N"] and r["same_x"], (rank, name, r)
+
+
+def test_stepped_api_world1_matches_run():
+    """ShardedEngine with a single rank (no process group) == Engine.run."""
+    from ellp_amd import _engine as E
+    from ellp_amd.dist import ShardedEngine
+    opts = E.default_opts(max_iter=None)
+    a = _flat(7, 40, 90)
+    e1 = E.Engine(E.ENGINE_PRIMAL, a, opts)
+    st1, s1, _ = e1.run(100000)
+    e1.read_point()
+    e1.close()
+    b = _flat(7, 40, 90)
+    e2 = ShardedEngine(E.ENGINE_PRIMAL, b, opts)
+    st2, s2, _ = e2.run(100000)
+    e2.read_point()
+    e2.close()
+    assert st1 == st2 == E.OPTIMAL and s1.iters == s2.iters
+    np.testing.assert_array_equal(a.B, b.B)
+    np.testing.assert_array_equal(a.x, b.x)
