@@ -90,7 +90,9 @@ def lib():
     L.ellp_engine_inverse_residual.argtypes = [C.c_void_p]
     L.ellp_engine_destroy.argtypes = [C.c_void_p]
     L.ellp_engine_set_shard.restype = C.c_int
-    L.ellp_engine_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.ellp_engine_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_segment_doubles.restype = C.c_int64
+    L.ellp_engine_segment_doubles.argtypes = [C.c_void_p, C.c_int]
     L.ellp_engine_exchange_info.restype = C.c_int
     L.ellp_engine_exchange_info.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -216,9 +218,12 @@ class Engine:
         return lib().ellp_engine_inverse_residual(self._h)
 
     # ---- sharded / stepped driving (see ellp_amd/dist.py)
-    def set_shard(self, rank, world):
+    def segment_doubles(self, world):
+        return int(lib().ellp_engine_segment_doubles(self._h, int(world)))
+
+    def set_shard(self, rank, world, buffer_ptr=None):
         err = C.create_string_buffer(512)
-        s = lib().ellp_engine_set_shard(self._h, int(rank), int(world), err, 512)
+        s = lib().ellp_engine_set_shard(self._h, int(rank), int(world), C.c_void_p(buffer_ptr), err, 512)
         if s != OPTIMAL:
             raise EllpHipError(s, err.value.decode())
 

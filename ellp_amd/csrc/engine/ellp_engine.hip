@@ -1866,7 +1866,8 @@ double ellp_engine_inverse_residual(ellp_engine *e) {
     return w;
 }
 
-ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, char *errbuf, size_t errlen) {
+ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exchange_buffer, char *errbuf,
+                                  size_t errlen) {
     if (!e || world < 1 || rank < 0 || rank >= world) {
         set_err(errbuf, errlen, "bad rank/world");
         return ELLP_ERR_ARG;
@@ -1877,11 +1878,17 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, char *err
     e->world = world;
     e->nbs = (e->nblocks + world - 1) / world;
     e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
-    double *nx = nullptr;
-    HIPCHK(dmalloc(e, &nx, (size_t)(e->seg * world)));
+    double *nx = static_cast<double *>(exchange_buffer);  // caller-owned (e.g. a torch tensor) ...
+    if (!nx) HIPCHK(dmalloc(e, &nx, (size_t)(e->seg * world)));  // ... or ours (released with the engine)
     HIPCHK(hipMemset(nx, 0, sizeof(double) * (size_t)(e->seg * world)));
-    e->X = nx;  // the previous buffer stays in e->allocs and is released with the engine
+    e->X = nx;
     return ELLP_OPTIMAL;
+}
+
+int64_t ellp_engine_segment_doubles(ellp_engine *e, int world) {
+    if (!e || world < 1) return ELLP_ERR_ARG;
+    const int64_t nbs = (e->nblocks + world - 1) / world;
+    return 2 * nbs + 2 * nbs * e->cpb;
 }
 
 ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_doubles, int *rank, int *world) {

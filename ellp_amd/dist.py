@@ -16,14 +16,6 @@ import numpy as np
 from . import _engine as E
 
 
-class _DevBuf:
-    """A raw device pointer dressed up for torch.as_tensor (CUDA array interface v2)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
 def shard_ranges(n_positions, cpb, world):
     """[(first, last+1)] nonbasic positions priced by each rank (mirrors ellp_engine_set_shard)."""
     nblocks = (max(n_positions, 1) + cpb - 1) // cpb
@@ -66,15 +58,22 @@ class ShardedEngine:
         else:
             self.rank, self.world = 0, 1
         self.eng = E.Engine(kind, fp, opts)
-        self.eng.set_shard(self.rank, self.world)
-        base, seg, _, _ = self.eng.exchange_info()
-        self.seg = seg
-        self.full = torch.as_tensor(_DevBuf(base, seg * self.world), device="cuda")
+        # the exchange buffer is a torch allocation handed to the engine, so the collective
+        # library works on memory it knows
+        self.seg = seg = self.eng.segment_doubles(self.world)
+        self.full = torch.zeros(seg * self.world, dtype=torch.float64, device="cuda")
         self.send = torch.empty(seg, dtype=torch.float64, device="cuda")
-        # the engine's launches and the collective must be ordered: share torch's current stream
-        self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        self.eng.set_shard(self.rank, self.world, self.full.data_ptr())
+        # The engine's launches, the staging copy and the collective must be ordered on ONE
+        # stream.  It has to be a real (non-null) stream: handle 0 would mean "the engine's own
+        # stream", which is non-blocking and unordered with torch's default stream.
+        self.stream = torch.cuda.Stream()
+        assert self.stream.cuda_stream != 0
+        self.eng.set_stream(self.stream.cuda_stream)
 
     def exchange(self):
+        """Must be called with self.stream current (run() does)."""
         if self.world == 1:
             return
         self.send.copy_(self.full[self.rank * self.seg:(self.rank + 1) * self.seg])
@@ -83,21 +82,22 @@ class ShardedEngine:
     def run(self, max_iters, poll_interval=16):
         """Up to `max_iters` further iterations; returns (status, Stats, message) like Engine.run."""
         done = 0
-        status, stats, msg = self.eng.poll()
-        while status == E.MAXITER and done < max_iters:
-            batch = min(poll_interval, max_iters - done)
-            for _ in range(batch):
-                self.eng.step(0)
-                self.exchange()
-                self.eng.step(1)
-            done += batch
+        with self.torch.cuda.stream(self.stream):
             status, stats, msg = self.eng.poll()
+            while status == E.MAXITER and done < max_iters:
+                batch = min(poll_interval, max_iters - done)
+                for _ in range(batch):
+                    self.eng.step(0)
+                    self.exchange()
+                    self.eng.step(1)
+                done += batch
+                status, stats, msg = self.eng.poll()
         return status, stats, msg
 
     def read_point(self):
         return self.eng.read_point()
 
     def close(self):
-        self.torch.cuda.current_stream().synchronize()
+        self.stream.synchronize()
         self.eng.set_stream(None)
         self.eng.close()

@@ -169,13 +169,19 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index,
  * ellp_engine_step(e, 1) [FTRAN + ratio test + eta update] the caller all-gathers that buffer
  * (RCCL over xGMI via torch.distributed, see ellp_amd/dist.py); everything else is replicated on
  * every rank and deterministic, so all ranks take the same pivots.
- *   set_shard   : choose (rank, world) before the first step; re-allocates the exchange buffer
+ *   segment_doubles: doubles per rank segment for a given world size
+ *   set_shard   : choose (rank, world) before the first step; exchange_buffer = caller-owned
+ *                 device memory of world*segment_doubles doubles (e.g. a torch tensor's data_ptr,
+ *                 so the collective library sees its own allocation), or NULL to let the engine
+ *                 allocate it
  *   exchange_info: device pointer of the buffer, doubles per segment, rank, world
  *   set_stream  : run the engine's launches on a caller-owned HIP stream (NULL = its own)
  *   step        : enqueue one half-iteration (never blocks)
  *   poll        : copy the status word back; ELLP_MAXITER = still running
  */
-ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, char *errbuf, size_t errbuf_len);
+int64_t ellp_engine_segment_doubles(ellp_engine *e, int world);
+ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exchange_buffer, char *errbuf,
+                                  size_t errbuf_len);
 ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_doubles, int *rank, int *world);
 ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream);
 ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t errbuf_len);

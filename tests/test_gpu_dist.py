@@ -76,10 +76,19 @@ def test_sharded_engine_takes_the_same_pivots_world2():
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
+        p.daemon = True
         p.start()
-    results = [q.get(timeout=300) for _ in range(world)]
+    try:
+        results = [q.get(timeout=150) for _ in range(world)]
+    except Exception:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
         assert p.exitcode == 0
     for rank, out in results:
         for name, r in out.items():
