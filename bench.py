@@ -137,12 +137,21 @@ def main():
     # N>1: the ranks cooperate on ONE pivot stream (pricing sharded, the rest replicated)
     pivots_per_s = args.steps / dt
     price_bytes = 8.0 * ld * nN
+    # HBM traffic of the pricing kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE, gfx950 x2 read correction) — only valid for the workload it was measured on
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_v3_pmc_traffic.json")))
+        if pm.get("workload") == f"m={m} n={n} primal" and world == 1:
+            traffic = pm["kernels"]["k_price<4, 0>"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = None
     if "price" in prof:
         t_us = prof["price"]["avg_us"]
         ach = price_bytes / (t_us * 1e-6) / 1e9
         roofline = {"kernel": "k_price", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": price_bytes, "avg_us": round(t_us, 3)}
     cpu = None
     cpu_pivots = args.cpu_pivots
