@@ -84,6 +84,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) but NOT
+// for outstanding global loads (vmcnt), so register prefetches issued earlier stay in flight
+// across it.  __syncthreads() carries a fence that drains vmcnt as well.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
@@ -276,24 +281,59 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ primal entering fold (one wave)
+// ------------------------------------------------------------------ primal entering fold
 // Exact emulation of the reference's sequential `max_by` fold (primal…:271-287): candidate
 // (key, N.index) replaces the accumulator iff NOT(|acc-key| >= EPS ? acc > key : acc.index >
-// index).  The comparator is not transitive, so the fold cannot be a tree reduction; instead a
-// wave walks the pricing blocks in position order and uses ballots to skip everything that
-// cannot change the accumulator: a block whose maximum key is <= acc - EPS holds no such
-// element.  Work is O(#blocks/64 + #accumulator changes).  s_bk = block maxima staged in LDS.
-__device__ __forceinline__ long long entering_fold(const double *s_bk, int nblocks, int cpb, int64_t nN,
-                                                   const Xchg &xc, const int64_t *N_index, double eps,
-                                                   int lane) {
-    bool have = false;
-    double racc = 0.0;
-    long long iacc = 0, qacc = -1;
+// index).  The comparator is not transitive, so the fold cannot be a tree reduction.
+//
+// fold_elements(): one wave feeds the 64-column chunk of one pricing block through the fold.
+// entering_fold_full(): walks ALL pricing blocks in position order, using ballots to skip every
+//   block whose maximum key is <= acc - EPS (it cannot change the accumulator).
+// Fast path (k_ftran2).  Let M be the maximum key, T = M - 4 EPS, and suppose NO key lies in the
+//   gap (T - 2 EPS, T].  Then every element above T beats every element below the gap by more
+//   than EPS and never ties with it.  So in the reference's fold (i) the first above-T element
+//   replaces whatever the accumulator was (or finds it empty) — the state after it is that
+//   element exactly; (ii) from then on the accumulator stays above T, and a below-gap element
+//   can neither beat it nor tie with it, i.e. it is never an event.  Hence folding only the
+//   blocks that contain an above-T element, in order, from an empty accumulator, ends in the
+//   same state (below-gap elements inside those blocks are harmless: one can only be the
+//   accumulator before the first above-T element, which replaces it).  The gap is CHECKED —
+//   per block on the block maxima, per element on the blocks that are opened — and the full
+//   walk runs if it is not clean.  Typically one block is opened, fetched in one round trip.
+struct FoldState {
+    bool have;
+    double racc;
+    long long iacc, qacc;
+};
+__device__ __forceinline__ void fold_elements(FoldState &f, double k, long long idx, int64_t jb, double eps,
+                                              int lane) {
+    int efrom = 0;
+    for (;;) {
+        bool ev = lane >= efrom && k > -INFINITY;
+        if (ev && f.have) {
+            const bool acc_greater = (fabs(f.racc - k) >= eps) ? (f.racc > k) : (f.iacc > idx);
+            ev = !acc_greater;
+        }
+        const unsigned long long em = __ballot(ev);
+        if (!em) break;
+        const int l = __ffsll((long long)em) - 1;
+        f.racc = __shfl(k, l);
+        f.iacc = __shfl(idx, l);
+        f.qacc = jb + l;
+        f.have = true;
+        efrom = l + 1;
+    }
+}
+
+__device__ __forceinline__ long long entering_fold_full(const double *s_bk, int nblocks, int cpb, int64_t nN,
+                                                        const Xchg &xc, const int64_t *N_index, double eps,
+                                                        int lane) {
+    FoldState f{false, 0.0, 0, -1};
     for (int g0 = 0; g0 < nblocks; g0 += WAVE) {
         const double bm = (g0 + lane < nblocks) ? s_bk[g0 + lane] : -INFINITY;
         int from = 0;
         for (;;) {
-            const bool pred = lane >= from && bm > -INFINITY && (!have || bm > racc - eps);
+            const bool pred = lane >= from && bm > -INFINITY && (!f.have || bm > f.racc - eps);
             const unsigned long long mask = __ballot(pred);
             if (!mask) break;
             const int bl = __ffsll((long long)mask) - 1;
@@ -302,31 +342,20 @@ __device__ __forceinline__ long long entering_fold(const double *s_bk, int nbloc
             const bool valid = lane < cpb && j < nN;
             const double k = valid ? xc.key(j) : -INFINITY;
             const long long idx = valid ? N_index[j] : 0;
-            int efrom = 0;
-            for (;;) {
-                bool ev = lane >= efrom && k > -INFINITY;
-                if (ev && have) {
-                    const bool acc_greater = (fabs(racc - k) >= eps) ? (racc > k) : (iacc > idx);
-                    ev = !acc_greater;
-                }
-                const unsigned long long em = __ballot(ev);
-                if (!em) break;
-                const int l = __ffsll((long long)em) - 1;
-                racc = __shfl(k, l);
-                iacc = __shfl(idx, l);
-                qacc = jb + l;
-                have = true;
-                efrom = l + 1;
-            }
+            fold_elements(f, k, idx, jb, eps, lane);
             from = bl + 1;
         }
     }
-    return qacc;
+    return f.qacc;
 }
+
+constexpr int FC_SLOTS = 16;
 
 // ------------------------------------------------------------------ FTRAN (+ decision prologue)
 // d = +-B^-1 a_q (primal…:295-300, dual…:294): one wave per row of the row-major W, 16 B per
-// lane, eight 16-byte loads per lane in flight; a_q (8*ld bytes) is re-read through L1/L2.
+// lane.  The row loads do not depend on the entering column, so each wave issues its (first)
+// row into registers BEFORE the decision prologue and the HBM stream overlaps the fold; the
+// column a_q (8*ld bytes, L2-resident) is fetched once q is known.
 // Prologue, every block: MODE 0 the entering fold over the pricing output, MODE 1 the dual
 // ratio argmin over the per-block minima (dual…:279, min_by keeps the FIRST minimum).
 // Epilogue MODE 0: the wave that produced d_i also evaluates the ratio lambda_i of basic row i
@@ -346,36 +375,180 @@ struct Ftran2Args {
     double eps;
 };
 
-template <int MODE>
+// NT = double2 per lane that hold one row (ceil(ld/128)); NT == 0: rows are streamed instead
+template <int MODE, int NT>
 __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ long long s_q;
     __shared__ double s_wk[4];
     __shared__ long long s_wp[4];
+    __shared__ int s_nh, s_band;
+    __shared__ int s_hblk[FC_SLOTS];
+    __shared__ double s_hkey[FC_SLOTS * 64];
+    __shared__ int32_t s_hidx[FC_SLOTS * 64];
     DevState *st = a.st;
     if (st->status != ST_RUNNING) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nan_flag = st->nan_flag;
     const int cur = st->cur;
+    const double *W = cur ? a.W1 : a.W0;
+    const int64_t half = a.ld >> 1;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+
+    constexpr int NTR = NT > 0 ? NT : 1;
+    double2 wrow[NTR];
+    int64_t bi0 = 0;
+    double xi0 = 0.0, lbi0 = 0.0, ubi0 = 0.0;
+    int k0 = 0;
     double theta_d = 0.0;
     if (MODE == 0) {
         double *s_bk = reinterpret_cast<double *>(smem);
-        for (int b0 = tid; b0 < a.nblocks; b0 += 4 * 256) {
+        double tmax = -INFINITY;
+        double v0[4];  // first (normally only) batch of block maxima: issued before the row prefetch
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = tid + 256 * u;
+            const double t = a.xc.bk(b < a.nblocks ? b : 0);  // clamped, unconditional
+            v0[u] = b < a.nblocks ? t : -INFINITY;
+        }
+        // ---- this wave's first row (and its ratio-test inputs): independent of the decision, so
+        // issue them now (after the small staging loads, which must retire first) and let the
+        // HBM stream overlap the fold.  sched_barrier: vmcnt retires in issue order, so the
+        // scheduler must not hoist this big batch above the loads the prologue waits for.
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // unconditional (clamped) so that every path has the same number of loads in flight —
+            // otherwise the waits below degrade to vmcnt(0)
+            const int64_t irow = wave_global < a.m ? wave_global : 0;
+            if (NT > 0) {
+                const double2 *row = reinterpret_cast<const double2 *>(W + irow * a.ld);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int64_t t = lane + u * WAVE;
+                    const double2 wv = row[t < half ? t : 0];
+                    wrow[u] = t < half ? wv : make_double2(0.0, 0.0);
+                }
+            }
+            if (MODE == 0) {
+                bi0 = a.B_index[irow];
+                xi0 = a.x[bi0];
+                k0 = a.kind[bi0];
+                lbi0 = a.lb[bi0];
+                ubi0 = a.ub[bi0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (tid + 256 * u < a.nblocks) s_bk[tid + 256 * u] = v0[u];
+            tmax = fmax(tmax, v0[u]);
+        }
+        for (int b0 = tid + 4 * 256; b0 < a.nblocks; b0 += 4 * 256) {
             double v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = (b0 + 256 * u < a.nblocks) ? a.xc.bk(b0 + 256 * u) : 0.0;
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + 256 * u;
+                const double t = a.xc.bk(b < a.nblocks ? b : 0);
+                v[u] = b < a.nblocks ? t : -INFINITY;
+            }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
                 if (b0 + 256 * u < a.nblocks) s_bk[b0 + 256 * u] = v[u];
+                tmax = fmax(tmax, v[u]);
+            }
         }
-        __syncthreads();
+        if (tid == 0) {
+            s_nh = 0;
+            s_band = 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o));
+        if (lane == 0) s_wk[wave] = tmax;
+        lds_barrier();
+        const double M = fmax(fmax(s_wk[0], s_wk[1]), fmax(s_wk[2], s_wk[3]));
+        // H = blocks within 4 EPS of the maximum; band = blocks in the next 2 EPS
+        for (int b = tid; b < a.nblocks; b += 256) {
+            const double v = s_bk[b];
+            if (v > M - 4.0 * a.eps) {
+                const int slot = atomicAdd(&s_nh, 1);
+                if (slot < FC_SLOTS) s_hblk[slot] = b;
+            } else if (v > M - 6.0 * a.eps) {
+                s_band = 1;
+            }
+        }
+        lds_barrier();
+        const int nh = s_nh;
+        const bool fast = M > -INFINITY && nh <= FC_SLOTS && !s_band;
+        if (fast) {
+            if (tid == 0) {  // order the (few) H blocks by position
+                for (int i = 1; i < nh; ++i) {
+                    const int v = s_hblk[i];
+                    int j = i - 1;
+                    while (j >= 0 && s_hblk[j] > v) {
+                        s_hblk[j + 1] = s_hblk[j];
+                        --j;
+                    }
+                    s_hblk[j + 1] = v;
+                }
+            }
+            lds_barrier();
+            for (int sl = wave; sl < nh; sl += 4) {  // all waves fetch the H blocks: one round trip
+                const int64_t j = (int64_t)s_hblk[sl] * a.cpb + lane;
+                const bool ok = lane < a.cpb && j < a.nN;
+                const int64_t jc = ok ? j : 0;
+                const double kl = a.xc.key(jc);
+                const int64_t il = a.N_index[jc];
+                const double kv = ok ? kl : -INFINITY;
+                s_hkey[sl * 64 + lane] = kv;
+                s_hidx[sl * 64 + lane] = ok ? (int32_t)il : 0;
+                if (kv > M - 6.0 * a.eps && !(kv > M - 4.0 * a.eps)) s_band = 1;  // an element in the gap
+            }
+            lds_barrier();
+        }
         if (wave == 0) {
-            const long long q = entering_fold(s_bk, a.nblocks, a.cpb, a.nN, a.xc, a.N_index, a.eps, lane);
+            long long q = -1;
+            bool done = false;
+            if (fast && !s_band) {
+                FoldState f{false, 0.0, 0, -1};
+                for (int sl = 0; sl < nh; ++sl)
+                    fold_elements(f, s_hkey[sl * 64 + lane], s_hidx[sl * 64 + lane], (int64_t)s_hblk[sl] * a.cpb,
+                                  a.eps, lane);
+                q = f.qacc;
+                done = true;
+            }
+            if (!done && M > -INFINITY)
+                q = entering_fold_full(s_bk, a.nblocks, a.cpb, a.nN, a.xc, a.N_index, a.eps, lane);
             if (lane == 0) s_q = q;
         }
-        __syncthreads();
+        lds_barrier();
     } else {
         if (st->lr < 0) return;  // k_price<.,1> block 0 has already reported Optimal
+        // ---- this wave's first row (and its ratio-test inputs): independent of the decision, so
+        // issue them now (after the small staging loads, which must retire first) and let the
+        // HBM stream overlap the fold.  sched_barrier: vmcnt retires in issue order, so the
+        // scheduler must not hoist this big batch above the loads the prologue waits for.
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // unconditional (clamped) so that every path has the same number of loads in flight —
+            // otherwise the waits below degrade to vmcnt(0)
+            const int64_t irow = wave_global < a.m ? wave_global : 0;
+            if (NT > 0) {
+                const double2 *row = reinterpret_cast<const double2 *>(W + irow * a.ld);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    const int64_t t = lane + u * WAVE;
+                    const double2 wv = row[t < half ? t : 0];
+                    wrow[u] = t < half ? wv : make_double2(0.0, 0.0);
+                }
+            }
+            if (MODE == 0) {
+                bi0 = a.B_index[irow];
+                xi0 = a.x[bi0];
+                k0 = a.kind[bi0];
+                lbi0 = a.lb[bi0];
+                ubi0 = a.ub[bi0];
+            }
+        }
         double bk = INFINITY;
         long long bp = -1;
         for (int b = tid; b < a.nblocks; b += 256) {
@@ -400,7 +573,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
             s_wk[wave] = bk;
             s_wp[wave] = bp;
         }
-        __syncthreads();
+        lds_barrier();
         bk = s_wk[0];
         bp = s_wp[0];
         for (int w = 1; w < 4; ++w)
@@ -410,7 +583,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
             }
         if (tid == 0) s_q = bp;
         theta_d = (st->ldelta < 0.0) ? -bk : bk;  // dual…:286-289
-        __syncthreads();
+        lds_barrier();
     }
     const long long q = s_q;
     if (nan_flag) {
@@ -427,38 +600,51 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     }
     const int at_lower = (MODE == 0) ? (a.Nb[q] == ELLP_NB_LOWER ? 1 : 0) : 0;
     const double sgn = at_lower ? -1.0 : 1.0;
-    const double *W = cur ? a.W1 : a.W0;
     const double2 *col = reinterpret_cast<const double2 *>(a.A_N + q * a.ld);
-    const int64_t half = a.ld >> 1;
-    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wave;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t i = wave_global; i < a.m; i += nwaves) {
+    bool first = true;
+    for (int64_t i = wave_global; i < a.m; i += nwaves, first = false) {
         const double2 *row = reinterpret_cast<const double2 *>(W + i * a.ld);
+        int64_t bi = bi0;
+        double xi = xi0, lbi = lbi0, ubi = ubi0;
+        int k = k0;
+        if (MODE == 0 && !first) {
+            bi = a.B_index[i];
+            xi = a.x[bi];
+            k = a.kind[bi];
+            lbi = a.lb[bi];
+            ubi = a.ub[bi];
+        }
         double acc0 = 0.0, acc1 = 0.0;
-        for (int64_t t0 = lane; t0 < half; t0 += 8 * WAVE) {
-            double2 w[8], c[8];
+        if (NT > 0 && first) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t t = t0 + u * WAVE;
-                w[u] = t < half ? row[t] : make_double2(0.0, 0.0);
-                c[u] = t < half ? col[t] : make_double2(0.0, 0.0);
+            for (int u = 0; u < NT; ++u) {
+                const int64_t t = lane + u * WAVE;
+                const double2 c = t < half ? col[t] : make_double2(0.0, 0.0);
+                acc0 = fma(wrow[u].x, c.x, acc0);
+                acc1 = fma(wrow[u].y, c.y, acc1);
             }
+        } else {
+            for (int64_t t0 = lane; t0 < half; t0 += 8 * WAVE) {
+                double2 w[8], c[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                acc0 = fma(w[u].x, c[u].x, acc0);
-                acc1 = fma(w[u].y, c[u].y, acc1);
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t t = t0 + u * WAVE;
+                    w[u] = t < half ? row[t] : make_double2(0.0, 0.0);
+                    c[u] = t < half ? col[t] : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc0 = fma(w[u].x, c[u].x, acc0);
+                    acc1 = fma(w[u].y, c[u].y, acc1);
+                }
             }
         }
         const double di = sgn * wave_sum(acc0 + acc1);
         if (lane == 0) {
             a.d[i] = di;
             if (MODE == 0) {
-                const int64_t bi = a.B_index[i];
                 double li = INFINITY;
                 if (!(fabs(di) < a.eps)) {
-                    const double xi = a.x[bi];
-                    const int k = a.kind[bi];
-                    const double lbi = a.lb[bi], ubi = a.ub[bi];
                     if (k == ELLP_BOUND_FREE) {
                         li = INFINITY;
                     } else if (k == ELLP_BOUND_LOWER) {
@@ -491,8 +677,8 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
             const int64_t jq = a.N_index[q];
             st->s_jq = jq;
             st->s_rq = a.xc.r(q);
-            const int k = a.kind[jq];  // primal…:305-311
-            st->s_lambda0 = (k == ELLP_BOUND_TWOSIDED) ? a.ub[jq] - a.lb[jq] : (k == ELLP_BOUND_FIXED ? 0.0 : INFINITY);
+            const int kk = a.kind[jq];  // primal…:305-311
+            st->s_lambda0 = (kk == ELLP_BOUND_TWOSIDED) ? a.ub[jq] - a.lb[jq] : (kk == ELLP_BOUND_FIXED ? 0.0 : INFINITY);
         } else {
             st->s_jq = a.N_index[q];
             st->s_r = st->lr;
@@ -556,46 +742,43 @@ __device__ __forceinline__ RatioResult ratio_fold(const double *chunkmin, int nc
     return RatioResult{lambda, nb, side};
 }
 
-// rows [row0, row0+nrows) of the eta update:
+// rows [row0, row0+nrows) (nrows <= 4) of the eta update:
 // dst[i,:] = src[i,:] - (d_i/d_r) * src[r,:]   (i != r),   dst[r,:] = src[r,:] / alpha_r.
-// Four rows per pass: every thread keeps four independent 16-byte loads in flight and re-uses
-// its chunk of the pivot row for all of them.
+// The (up to) four rows go through together: every thread keeps four independent 16-byte loads
+// in flight and re-uses its chunk of the pivot row for all of them.  dv[k] = d[row0+k] is loaded
+// by the caller ahead of time (it does not depend on the pivot row).
+constexpr int UPD_ROWS = 4;
 __device__ __forceinline__ void eta_update_rows(const double *src, double *dst, int64_t m, int64_t ld, int64_t r,
-                                                const double *d, double d_r, double alpha_r, int64_t row0,
-                                                int nrows, int tid) {
-    constexpr int UPD_ROWS = 4;
+                                                const double dv[UPD_ROWS], double d_r, double alpha_r,
+                                                int64_t row0, int nrows, int tid) {
     const int64_t half = ld >> 1;
     const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * ld);
-    for (int rr = 0; rr < nrows; rr += UPD_ROWS) {
-        const int64_t i0 = row0 + rr;
-        if (i0 >= m) break;
-        double f[UPD_ROWS];
-        int64_t ii[UPD_ROWS];
+    double f[UPD_ROWS];
+    int64_t ii[UPD_ROWS];
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) {
+        const int64_t i = row0 + k;
+        const bool ok = i < m && k < nrows;
+        ii[k] = ok ? i : -1;
+        f[k] = (ok && i != r) ? -(dv[k] / d_r) : 0.0;
+    }
+    for (int64_t t = tid; t < half; t += 256) {
+        const double2 p = rho2[t];
+        double2 w[UPD_ROWS];
+#pragma unroll
+        for (int k = 0; k < UPD_ROWS; ++k)
+            if (ii[k] >= 0) w[k] = reinterpret_cast<const double2 *>(src + ii[k] * ld)[t];
 #pragma unroll
         for (int k = 0; k < UPD_ROWS; ++k) {
-            const int64_t i = i0 + k;
-            const bool ok = i < m && rr + k < nrows;
-            ii[k] = ok ? i : -1;
-            f[k] = (ok && i != r) ? -(d[i] / d_r) : 0.0;
-        }
-        for (int64_t t = tid; t < half; t += 256) {
-            const double2 p = rho2[t];
-            double2 w[UPD_ROWS];
-#pragma unroll
-            for (int k = 0; k < UPD_ROWS; ++k)
-                if (ii[k] >= 0) w[k] = reinterpret_cast<const double2 *>(src + ii[k] * ld)[t];
-#pragma unroll
-            for (int k = 0; k < UPD_ROWS; ++k) {
-                if (ii[k] < 0) continue;
-                double2 o;
-                if (ii[k] == r) {
-                    o = make_double2(p.x / alpha_r, p.y / alpha_r);
-                } else {
-                    o.x = fma(f[k], p.x, w[k].x);
-                    o.y = fma(f[k], p.y, w[k].y);
-                }
-                reinterpret_cast<double2 *>(dst + ii[k] * ld)[t] = o;
+            if (ii[k] < 0) continue;
+            double2 o;
+            if (ii[k] == r) {
+                o = make_double2(p.x / alpha_r, p.y / alpha_r);
+            } else {
+                o.x = fma(f[k], p.x, w[k].x);
+                o.y = fma(f[k], p.y, w[k].y);
             }
+            reinterpret_cast<double2 *>(dst + ii[k] * ld)[t] = o;
         }
     }
 }
@@ -693,7 +876,8 @@ struct Update2Args {
     double eps;
 };
 
-template <int MODE>
+// NR = double2 per thread per row (ceil(ld/512)); NR == 0: rows are streamed after the fold
+template <int MODE, int NR>
 __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ double s_lambda;
@@ -711,6 +895,15 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     int64_t r;
     double lambda = 0.0;
     int side = 0;
+    // block 0 does the bookkeeping only; blocks 1.. stream rows_per_block (<= 4) rows each
+    const int64_t row0 = ((int64_t)blockIdx.x - 1) * a.rows_per_block;
+    double dv[UPD_ROWS];
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k)
+        dv[k] = (blockIdx.x > 0 && k < a.rows_per_block && row0 + k < m) ? a.d[row0 + k] : 0.0;
+    constexpr int NRR = NR > 0 ? NR : 1;
+    double2 wreg[UPD_ROWS][NRR];
+    const int64_t halfw = a.ld >> 1;
     if (MODE == 0) {
         const int nchunks = (int)((m + 63) >> 6);
         double *chunkmin = reinterpret_cast<double *>(smem);
@@ -720,21 +913,46 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         double *l_lam = chunkmin + nchunks;
         int32_t *l_bidx = reinterpret_cast<int32_t *>(l_lam + (a.stage_lds ? m : 0));
         uint8_t *l_dpos = reinterpret_cast<uint8_t *>(l_bidx + (a.stage_lds ? m : 0));
-        // each wave takes chunks wave, wave+4, ... ; 4 chunks (independent loads) per pass
-        for (int c0 = wave; c0 < nchunks; c0 += 16) {
-            double v[4];
-            int32_t bi[4];
-            uint8_t dp[4];
+        // each wave takes chunks wave, wave+4, ... ; 8 chunks (24 independent loads) per pass
+        bool rows_issued = false;
+        for (int c0 = wave; c0 < nchunks || !rows_issued; c0 += 32) {
+            double v[8];
+            int32_t bi[8];
+            uint8_t dp[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
+                // unconditional loads from a clamped index (a predicated load becomes a branch
+                // with its own wait: eight serialized round trips instead of one)
                 const int64_t i = (int64_t)(c0 + 4 * k) * 64 + lane;
                 const bool ok = (c0 + 4 * k) < nchunks && i < m;
-                v[k] = ok ? lam[i] : INFINITY;
-                bi[k] = (ok && a.stage_lds) ? bidx[i] : 0;
-                dp[k] = (ok && a.stage_lds) ? dpos[i] : 0;
+                const int64_t ic = ok ? i : 0;
+                const double lv = lam[ic];
+                bi[k] = bidx[ic];
+                dp[k] = dpos[ic];
+                v[k] = ok ? lv : INFINITY;
+            }
+            if (!rows_issued) {
+                rows_issued = true;
+        // The rows this block rewrites do not depend on which row pivots: issue them into
+            // registers now (behind the small staging loads) so the HBM stream overlaps the fold.
+            __builtin_amdgcn_sched_barrier(0);
+            if (NR > 0) {  // every block, block 0 included (clamped): same loads in flight on all paths
+#pragma unroll
+                for (int k = 0; k < UPD_ROWS; ++k) {
+                    const int64_t i = row0 + k;
+                    const bool ok = blockIdx.x > 0 && k < a.rows_per_block && i < m;
+                    const double2 *srow = reinterpret_cast<const double2 *>(src + (ok ? i : 0) * a.ld);
+#pragma unroll
+                    for (int u = 0; u < NR; ++u) {
+                        const int64_t t = tid + 256 * u;
+                        const double2 wv = srow[t < halfw ? t : 0];
+                        wreg[k][u] = (ok && t < halfw) ? wv : make_double2(0.0, 0.0);
+                    }
+                }
+            }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const int c = c0 + 4 * k;
                 if (c >= nchunks) continue;
                 const int64_t i = (int64_t)c * 64 + lane;
@@ -747,7 +965,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 if (lane == 0) chunkmin[c] = cm;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (wave == 0) {
             const RatioResult rr = a.stage_lds
                                        ? ratio_fold(chunkmin, nchunks, m, l_lam, l_bidx, l_dpos, st->s_lambda0, a.eps, lane)
@@ -758,7 +976,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 s_side = rr.side;
             }
         }
-        __syncthreads();
+        lds_barrier();
         lambda = s_lambda;
         r = s_nb;
         side = s_side;
@@ -783,6 +1001,23 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         }
     } else {
         r = st->s_r;
+        // The rows this block rewrites do not depend on which row pivots: issue them into
+        // registers now (behind the small staging loads) so the HBM stream overlaps the fold.
+        __builtin_amdgcn_sched_barrier(0);
+        if (NR > 0) {  // every block, block 0 included (clamped): same loads in flight on all paths
+#pragma unroll
+            for (int k = 0; k < UPD_ROWS; ++k) {
+                const int64_t i = row0 + k;
+                const bool ok = blockIdx.x > 0 && k < a.rows_per_block && i < m;
+                const double2 *srow = reinterpret_cast<const double2 *>(src + (ok ? i : 0) * a.ld);
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int64_t t = tid + 256 * u;
+                    const double2 wv = srow[t < halfw ? t : 0];
+                    wreg[k][u] = (ok && t < halfw) ? wv : make_double2(0.0, 0.0);
+                }
+            }
+        }
     }
 
     const int at_lower = st->s_at_lower;
@@ -790,8 +1025,40 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     if (r >= 0) {
         d_r = a.d[r];
         alpha_r = (MODE == 0 && at_lower) ? -d_r : d_r;
-        eta_update_rows(src, dst, m, a.ld, r, a.d, d_r, alpha_r, (int64_t)blockIdx.x * a.rows_per_block,
-                        a.rows_per_block, tid);
+        if (blockIdx.x > 0) {
+            if (NR > 0) {
+                const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
+                double2 pr[NRR];
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int64_t t = tid + 256 * u;
+                    const double2 pv = rho2[t < halfw ? t : 0];
+                    pr[u] = t < halfw ? pv : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int k = 0; k < UPD_ROWS; ++k) {
+                    const int64_t i = row0 + k;
+                    if (!(k < a.rows_per_block && i < m)) continue;
+                    const double f = (i != r) ? -(dv[k] / d_r) : 0.0;
+                    double2 *drow = reinterpret_cast<double2 *>(dst + i * a.ld);
+#pragma unroll
+                    for (int u = 0; u < NR; ++u) {
+                        const int64_t t = tid + 256 * u;
+                        if (t >= halfw) continue;
+                        double2 o;
+                        if (i == r) {
+                            o = make_double2(pr[u].x / alpha_r, pr[u].y / alpha_r);
+                        } else {
+                            o.x = fma(f, pr[u].x, wreg[k][u].x);
+                            o.y = fma(f, pr[u].y, wreg[k][u].y);
+                        }
+                        drow[t] = o;
+                    }
+                }
+            } else {
+                eta_update_rows(src, dst, m, a.ld, r, dv, d_r, alpha_r, row0, a.rows_per_block, tid);
+            }
+        }
     }
     if (blockIdx.x != 0) return;
 
@@ -1095,8 +1362,11 @@ __global__ __launch_bounds__(256) void k_ref_update(RefArgs a) {
     if (st->status != ST_RUNNING || !st->do_update) return;
     const double *src = st->cur ? a.W0 : a.W1;
     double *dst = st->cur ? a.W1 : a.W0;
-    eta_update_rows(src, dst, a.m, a.ld, st->r, a.d, st->d_r, st->alpha_r, (int64_t)blockIdx.x * a.rows_per_block,
-                    a.rows_per_block, threadIdx.x);
+    const int64_t row0 = (int64_t)blockIdx.x * a.rows_per_block;
+    double dv[UPD_ROWS];
+#pragma unroll
+    for (int k = 0; k < UPD_ROWS; ++k) dv[k] = (k < a.rows_per_block && row0 + k < a.m) ? a.d[row0 + k] : 0.0;
+    eta_update_rows(src, dst, a.m, a.ld, st->r, dv, st->d_r, st->alpha_r, row0, a.rows_per_block, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_ref_permute(RefArgs a) {
@@ -1317,7 +1587,12 @@ void launch_ftran2(ellp_engine *e) {
     a.x = e->x; a.lb = e->lb; a.ub = e->ub;
     a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.cpb = e->cpb; a.eps = e->eps;
-    hipLaunchKernelGGL(k_ftran2<MODE>, dim3(e->ftran_blocks), dim3(256), e->ftran_lds, e->stream, a);
+    const dim3 g(e->ftran_blocks), b(256);
+    const int64_t nt = ((e->ld >> 1) + 63) / 64;  // double2 per lane for one row
+    if (nt <= 4) hipLaunchKernelGGL((k_ftran2<MODE, 4>), g, b, e->ftran_lds, e->stream, a);
+    else if (nt <= 8) hipLaunchKernelGGL((k_ftran2<MODE, 8>), g, b, e->ftran_lds, e->stream, a);
+    else if (nt <= 16) hipLaunchKernelGGL((k_ftran2<MODE, 16>), g, b, e->ftran_lds, e->stream, a);
+    else hipLaunchKernelGGL((k_ftran2<MODE, 0>), g, b, e->ftran_lds, e->stream, a);
 }
 
 template <int MODE>
@@ -1328,7 +1603,14 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
-    hipLaunchKernelGGL(k_update2<MODE>, dim3(e->upd_blocks), dim3(256), MODE == 0 ? e->upd_lds : 0, e->stream, a);
+    const dim3 g(e->upd_blocks + 1), b(256);
+    const size_t lds = MODE == 0 ? e->upd_lds : 0;
+    const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
+    if (nr <= 1) hipLaunchKernelGGL((k_update2<MODE, 1>), g, b, lds, e->stream, a);
+    else if (nr <= 2) hipLaunchKernelGGL((k_update2<MODE, 2>), g, b, lds, e->stream, a);
+    else if (nr <= 4) hipLaunchKernelGGL((k_update2<MODE, 4>), g, b, lds, e->stream, a);
+    else if (nr <= 8) hipLaunchKernelGGL((k_update2<MODE, 8>), g, b, lds, e->stream, a);
+    else hipLaunchKernelGGL((k_update2<MODE, 0>), g, b, lds, e->stream, a);
 }
 
 void launch_btran(ellp_engine *e) {
