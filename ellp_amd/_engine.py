@@ -86,6 +86,8 @@ def lib():
     L.ellp_engine_tap.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
     L.ellp_engine_refactor.restype = C.c_int
     L.ellp_engine_refactor.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_refresh.restype = C.c_double
+    L.ellp_engine_refresh.argtypes = [C.c_void_p]
     L.ellp_engine_inverse_residual.restype = C.c_double
     L.ellp_engine_inverse_residual.argtypes = [C.c_void_p]
     L.ellp_engine_destroy.argtypes = [C.c_void_p]
@@ -213,6 +215,10 @@ class Engine:
         s = lib().ellp_engine_refactor(self._h, err, 512)
         if s != OPTIMAL:
             raise EllpHipError(s, err.value.decode())
+
+    def refresh(self):
+        """One Newton-Schulz step on B^-1; returns the residual before the step."""
+        return lib().ellp_engine_refresh(self._h)
 
     def inverse_residual(self):
         return lib().ellp_engine_inverse_residual(self._h)

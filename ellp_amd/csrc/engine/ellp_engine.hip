@@ -1386,6 +1386,132 @@ __global__ void k_ref_finish(RefArgs a) {
     a.st->do_update = 0;
 }
 
+// ------------------------------------------------------------------ Newton-Schulz refresh of B^-1
+// Between rebuilds the explicit inverse picks up rounding drift from the eta updates.  Instead of
+// re-deriving it column by column (m dependent steps), one Newton-Schulz step
+//     E = I - A_B W ;  W <- W + W E
+// squares the residual (|E| ~ 1e-12 -> rounding level) with two m x m x m f64 GEMMs and no
+// sequential dependency.  k_gemm128: 128 x 128 output tile per 256-thread block, 8 x 8
+// accumulators per thread, K-step 16 staged through LDS.
+//   AMODE 0: A(i,k) = A[k*ld + i] (column-major A_B)      OMODE 0: out = delta_ij - acc  (E)
+//   AMODE 1: A(i,k) = A[i*ld + k] (row-major W)            OMODE 1: out = Cin + acc       (W + W E)
+//   B(k,j) = B[k*ld + j] (row-major) in both uses.
+// WSEL picks operands from the two B^-1 buffers by st->cur on the device.
+struct GemmArgs {
+    double *W0, *W1;
+    const double *A_B;
+    double *T;         // third m x ld buffer
+    double *tilemax;   // per-tile max |out| (OMODE 0: the residual)
+    const DevState *st;
+    int64_t m, ld;
+};
+
+template <int STEP>  // STEP 0: E = I - A_B W[cur] -> W[cur^1] ; STEP 1: T = W[cur] + W[cur] E
+__global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
+    constexpr int BM = 128, BN = 128, BK = 16;
+    __shared__ double sA[BK][BM];
+    __shared__ double sB[BK][BN];
+    __shared__ double s_red[4];
+    if (a.st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int64_t m = a.m, ld = a.ld;
+    const double *Wc = a.st->cur ? a.W1 : a.W0;
+    double *Wo = a.st->cur ? a.W0 : a.W1;
+    const double *A = STEP == 0 ? a.A_B : Wc;
+    const double *B = STEP == 0 ? Wc : Wo;
+    double *C = STEP == 0 ? Wo : a.T;
+    const int64_t i0 = (int64_t)blockIdx.y * BM, j0 = (int64_t)blockIdx.x * BN;
+    double acc[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0.0;
+    for (int64_t k0 = 0; k0 < m; k0 += BK) {
+        // ---- stage A tile (BM x BK) and B tile (BK x BN)
+        if (STEP == 0) {  // column-major A: 128 contiguous i per k
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int kk = (tid >> 5) + 8 * p, i4 = (tid & 31) * 4;
+                const int64_t k = k0 + kk;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t i = i0 + i4 + c;
+                    sA[kk][i4 + c] = (k < m && i < m) ? A[k * ld + i] : 0.0;
+                }
+            }
+        } else {  // row-major A: 16 contiguous k per i
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int il = (tid >> 2) + 64 * p, k4 = (tid & 3) * 4;
+                const int64_t i = i0 + il;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t k = k0 + k4 + c;
+                    sA[k4 + c][il] = (k < m && i < m) ? A[i * ld + k] : 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int kk = (tid >> 5) + 8 * p, j4 = (tid & 31) * 4;
+            const int64_t k = k0 + kk;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t j = j0 + j4 + c;
+                sB[kk][j4 + c] = (k < m && j < m) ? B[k * ld + j] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) av[r] = sA[kk][ty * 8 + r];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bv[c] = sB[kk][tx * 8 + c];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+    double worst = 0.0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int64_t i = i0 + ty * 8 + r;
+        if (i >= m) continue;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int64_t j = j0 + tx * 8 + c;
+            if (j >= m) continue;
+            double o;
+            if (STEP == 0) o = (i == j ? 1.0 : 0.0) - acc[r][c];
+            else o = Wc[i * ld + j] + acc[r][c];
+            C[i * ld + j] = o;
+            worst = fmax(worst, fabs(o));
+        }
+    }
+    if (STEP == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
+        if ((tid & 63) == 0) s_red[tid >> 6] = worst;
+        __syncthreads();
+        if (tid == 0)
+            a.tilemax[blockIdx.y * gridDim.x + blockIdx.x] = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    }
+}
+
+// T -> W[cur^1], then cur ^= 1 (k_ref_finish)
+__global__ __launch_bounds__(256) void k_copy_to_other(GemmArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    double2 *dst = reinterpret_cast<double2 *>(a.st->cur ? a.W0 : a.W1);
+    const double2 *src = reinterpret_cast<const double2 *>(a.T);
+    const int64_t total = a.m * (a.ld >> 1);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) dst[t] = src[t];
+}
+
 // max |W A_B - I| (drift monitor, test/diagnostic only — m^3 work)
 __global__ __launch_bounds__(256) void k_inv_residual(const double *W0, const double *W1, const DevState *st,
                                                       const double *A_B, int64_t m, int64_t ld, double *out) {
@@ -1440,7 +1566,9 @@ struct ellp_engine {
     double *A_B = nullptr, *A_N = nullptr, *W = nullptr, *W2 = nullptr;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
-    double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr;
+    double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
+    uint64_t refreshes = 0;
+    double last_residual = 0.0;
     int64_t *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
     uint8_t *kindv = nullptr, *Nb = nullptr, *dpos = nullptr;
     int32_t *used = nullptr, *bidx = nullptr;
@@ -1636,6 +1764,38 @@ void launch_refactor(ellp_engine *e) {
     e->refactors += 1;
     e->since_refactor = 0;
     e->u_valid = false;
+}
+
+// One Newton-Schulz step on the current inverse.  Returns the residual max|I - A_B W| measured
+// BEFORE the step (host readback: one sync per refresh), or a negative value on a HIP error.
+// If the residual is too large for the iteration to be trusted the caller rebuilds instead.
+double launch_refresh(ellp_engine *e) {
+    Prof p(e, ELLP_K_REFACTOR);
+    GemmArgs a{e->W, e->W2, e->A_B, e->T, e->resid, e->st, e->m, e->ld};
+    const unsigned nt = (unsigned)((e->m + 127) / 128);
+    hipLaunchKernelGGL(k_gemm128<0>, dim3(nt, nt), dim3(256), 0, e->stream, a);
+    std::vector<double> tm((size_t)nt * nt);
+    if (hipMemcpyAsync(tm.data(), e->resid, sizeof(double) * tm.size(), hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+        return -1.0;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return -1.0;
+    double res = 0.0;
+    for (double v : tm) res = (v > res || v != v) ? v : res;
+    e->last_residual = res;
+    if (!(res < 1e-4)) return res;  // not a small perturbation any more: let the caller rebuild
+    hipLaunchKernelGGL(k_gemm128<1>, dim3(nt, nt), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_copy_to_other, dim3(1024), dim3(256), 0, e->stream, a);
+    RefArgs ra{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows, e->eps};
+    hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, e->stream, ra);
+    e->refreshes += 1;
+    e->since_refactor = 0;
+    e->u_valid = false;
+    return res;
+}
+
+// periodic maintenance of B^-1: Newton-Schulz refresh, full rebuild only if that is not safe
+void maintain_inverse(ellp_engine *e) {
+    const double res = launch_refresh(e);
+    if (!(res >= 0.0 && res < 1e-4)) launch_refactor(e);
 }
 
 void launch_primal_iteration(ellp_engine *e) {
@@ -1900,7 +2060,9 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->lam, (size_t)m));
     ECHK(dmalloc(e, &e->bidx, (size_t)m));
     ECHK(dmalloc(e, &e->dpos, (size_t)m));
-    ECHK(dmalloc(e, &e->resid, (size_t)m));
+    ECHK(dmalloc(e, &e->resid, (size_t)(m > 4096 ? m : 4096)));
+    ECHK(dmalloc(e, &e->T, (size_t)(m * ld)));
+    ECHK(hipMemsetAsync(e->T, 0, sizeof(double) * (size_t)(m * ld), e->stream));
     ECHK(dmalloc(e, &e->st, 1));
     ECHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_st), sizeof(DevState), hipHostMallocDefault));
     if (kind == ELLP_ENGINE_DUAL) {
@@ -2001,6 +2163,15 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     return ELLP_OPTIMAL;
 }
 
+double ellp_engine_refresh(ellp_engine *e) {
+    if (!e) return NAN;
+    if (hipSetDevice(e->device) != hipSuccess) return NAN;
+    const double res = launch_refresh(e);
+    (void)hipStreamSynchronize(e->stream);
+    prof_collect(e);
+    return res;
+}
+
 ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
@@ -2019,7 +2190,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : (e->m <= 256 ? 64 : 16);
     int64_t period = e->refactor_period;
-    if (period <= 0) period = 100;  // default; see DESIGN.md §numerics
+    if (period <= 0) period = 1000;  // default; see DESIGN.md §numerics
     ellp_status result = ELLP_MAXITER;
     if (e->nN == 0) {
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
@@ -2043,7 +2214,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         while (remaining > 0) {
             const uint64_t batch = remaining < poll ? remaining : poll;
             for (uint64_t it = 0; it < batch; ++it) {
-                if (e->since_refactor >= (uint64_t)period) launch_refactor(e);
+                if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
                 if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
                 else launch_dual_iteration(e);
             }
@@ -2063,7 +2234,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         stats->iters = e->h_st->iters;
         stats->pivots = e->h_st->pivots;
         stats->bound_flips = e->h_st->flips;
-        stats->refactors = e->refactors;
+        stats->refactors = e->refactors + e->refreshes;
         stats->obj = e->h_st->obj;
         stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         stats->t_setup_s = e->t_setup;
@@ -2195,8 +2366,8 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
     HIPCHK(hipSetDevice(e->device));
     if (e->nN == 0) return ELLP_OPTIMAL;
     if (phase == 0) {
-        int64_t period = e->refactor_period > 0 ? e->refactor_period : 100;
-        if (e->since_refactor >= (uint64_t)period) launch_refactor(e);
+        int64_t period = e->refactor_period > 0 ? e->refactor_period : 1000;
+        if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
         if (e->kind == ELLP_ENGINE_PRIMAL) {
             const bool full_btran =
                 (e->opts.btran_mode == 1) || !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;

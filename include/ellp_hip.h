@@ -193,7 +193,12 @@ enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_T
        ELLP_TAP_ALPHA = 5 };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
-/* Forces a refactorisation of B^-1 now (used by tests and by the drift monitor). */
+/* One Newton-Schulz step W <- W + W (I - A_B W) on the resident inverse (two f64 GEMMs); this
+ * is what the engine does every `refactor_period` iterations.  Returns max|I - A_B W| measured
+ * before the step (NaN on error); if that is >= 1e-4 nothing is changed (rebuild instead). */
+double ellp_engine_refresh(ellp_engine *e);
+
+/* Forces a full rebuild of B^-1 from A_B now (used by tests and when a refresh is not safe). */
 ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errbuf_len);
 
 /* max_ij |(B^-1 A_B - I)_ij| computed on device (drift monitor; tests). */

@@ -173,3 +173,46 @@ def test_dual_netlib(fx):
     status, fp2 = out
     assert status == "optimal"
     assert abs(fp2.obj() / fx["obj"] - 1.0) < 1e-6
+
+
+def test_newton_schulz_refresh_restores_the_inverse():
+    """After many eta updates max|W A_B - I| has drifted; one refresh (two f64 GEMMs) brings it
+    back to rounding level, and the solve then continues to the oracle's optimum."""
+    E = _engine()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(20260301, 200, 500)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                       f["x"], f["B"], f["N"], f["Nb"])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, refactor_period=1 << 30))
+    st, stats, _ = eng.run(400)
+    assert st == E.MAXITER and stats.iters == 400
+    before = eng.inverse_residual()
+    reported = eng.refresh()
+    after = eng.inverse_residual()
+    # refresh reports max|I - A_B W| (right residual), inverse_residual max|W A_B - I| (left): same size
+    assert 0.1 * before <= reported <= 10 * before + 1e-15, (before, reported)
+    assert after < 1e-12 and after <= max(before, 2e-13), (before, after)
+    st, stats, msg = eng.run(1 << 40)
+    eng.read_point()
+    eng.close()
+    assert st == E.OPTIMAL, msg
+    assert abs(fp.obj()) < 1e-8  # phase 1 of a feasible LP ends at objective 0
+
+
+def test_default_maintenance_period_full_solve():
+    """Full primal solve with the default maintenance (refresh every 1000 iterations) against the
+    oracle: same optimum (the pivot path may differ after a refresh)."""
+    E = _engine()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(20260301, 200, 500)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                       f["x"], f["B"], f["N"], f["Nb"])
+    st, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=None, refactor_period=250))
+    assert st == E.OPTIMAL, msg
+    assert stats.refactors >= 2  # initial rebuild + at least one Newton-Schulz refresh
+    f2 = synth.primal_phase2_from(f, fp.x, fp.B, fp.N, fp.Nb)
+    fp2 = E.FlatProblem(f2["m"], f2["n"], f2["n_c"], f2["A"], f2["c"], f2["b"], f2["kind"], f2["lb"], f2["ub"],
+                        f2["x"], f2["B"], f2["N"], f2["Nb"])
+    st, stats, msg = E.primal_solve_with_initial(fp2, E.default_opts(max_iter=None, refactor_period=250))
+    assert st == E.OPTIMAL, msg
+    assert abs(fp2.obj() - (-251.6515333670212)) < 1e-7  # SURVEY §8d: independent HiGHS objective, 200 x 500
