@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--n", type=int, default=5000)
     ap.add_argument("--seed", type=int, default=20260301)
-    ap.add_argument("--solver", choices=["primal"], default="primal")
+    ap.add_argument("--solver", choices=["primal", "dual"], default="primal")
     ap.add_argument("--cpu-pivots", type=int, default=-1, help="oracle pivots to time (-1 auto, 0 off)")
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--refactor-period", type=int, default=0)
@@ -41,7 +41,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(flat, pivots):
+def cpu_baseline(flat, pivots, solver="primal"):
     """The oracle's loop (LU refactorisation every iteration, single thread — the reference's
     algorithm) timed on this host over a bounded window from the same starting basis."""
     from oracle import ellp_oracle as eo
@@ -56,9 +56,14 @@ def cpu_baseline(flat, pivots):
     v.N = flat["N"].copy()
     v.Nb = flat["Nb"].copy()
     v.nB, v.nN = len(v.B), len(v.N)
+    if solver == "dual":
+        v.y, v.d = flat["y"].copy(), flat["d"].copy()
     eo.set_dense_lu(True)  # pay nalgebra's full (2/3) m^3 per iteration, as the reference does
     t0 = time.perf_counter()
-    st, iters, _ = eo.primal_solve_with_initial(v, pivots)
+    if solver == "dual":
+        st, iters, _ = eo.dual_solve_with_initial(v, pivots)
+    else:
+        st, iters, _ = eo.primal_solve_with_initial(v, pivots)
     dt = time.perf_counter() - t0
     eo.set_dense_lu(False)
     return iters / dt, iters, dt, v
@@ -83,9 +88,12 @@ def main():
     from ellp_amd import synth
 
     m, n = args.m, args.n
-    flat = synth.primal_phase1_flat(args.seed, m, n)
+    dual = args.solver == "dual"
+    flat = synth.dual_start_flat(args.seed, m, n) if dual else synth.primal_phase1_flat(args.seed, m, n)
     fp = E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
-                       flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"])
+                       flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"],
+                       flat.get("y"), flat.get("d"))
+    kind = E.ENGINE_DUAL if dual else E.ENGINE_PRIMAL
     nN = fp.nN
     ld = (m + 15) // 16 * 16
 
@@ -95,8 +103,8 @@ def main():
         if world > 1:
             # column-block pricing sharded over the ranks, one RCCL all-gather per iteration
             from ellp_amd.dist import ShardedEngine
-            return ShardedEngine(E.ENGINE_PRIMAL, fp, opts)
-        return E.Engine(E.ENGINE_PRIMAL, fp, opts)
+            return ShardedEngine(kind, fp, opts)
+        return E.Engine(kind, fp, opts)
 
     # ---- timed region: tableau resident, W warm-up steps, then exactly K steps
     eng = make_engine(0)
@@ -142,15 +150,16 @@ def main():
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01b_v3_pmc_traffic.json")))
-        if pm.get("workload") == f"m={m} n={n} primal" and world == 1:
+        if pm.get("workload") == f"m={m} n={n} {args.solver}" and world == 1:
             traffic = pm["kernels"]["k_price<4, 0>"]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
     roofline = None
-    if "price" in prof:
-        t_us = prof["price"]["avg_us"]
+    pk = "dprice" if dual else "price"
+    if pk in prof:
+        t_us = prof[pk]["avg_us"]
         ach = price_bytes / (t_us * 1e-6) / 1e9
-        roofline = {"kernel": "k_price", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"kernel": "k_price<T,1>" if dual else "k_price<T,0>", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": price_bytes, "avg_us": round(t_us, 3)}
     cpu = None
@@ -160,18 +169,20 @@ def main():
         est = (2.0 / 3.0) * m ** 3 / 2.5e9 + 1e-3
         cpu_pivots = int(max(3, min(2000, 15.0 / est)))
     if cpu_pivots > 0:
-        rate, iters, cdt, _ = cpu_baseline(flat, cpu_pivots)
+        rate, iters, cdt, _ = cpu_baseline(flat, cpu_pivots, args.solver)
         cpu = {"value": round(rate, 4), "unit": "pivots/s", "cores": 1, "kind": "port",
                "sample": f"first {iters} pivots of the same LP from the same starting basis, {cdt:.1f} s, "
                          "oracle/ellp_oracle.c (LU refactor every iteration, single thread)"}
-    alg_bytes_per_pivot = 8.0 * ld * nN + 32.0 * m * ld
+    alg_bytes_per_pivot = 8.0 * ld * nN + (24.0 if dual else 32.0) * m * ld
     out = {
-        "metric": "simplex pivots/sec (dense LP, primal, tableau resident in HBM)",
+        "metric": f"simplex pivots/sec (dense LP, {args.solver}, tableau resident in HBM)",
         "value": round(pivots_per_s, 2), "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 6), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"random dense LP m={m} n={n} (seed {args.seed}), primal simplex phase 1, "
-                               f"std-form {m}x{fp.n} with |N|={nN}", "refactors_in_window": int(refactors),
+        "config": {"workload": (f"random dense covering LP m={m} n={n} (seed {args.seed}), dual simplex from the "
+                                f"slack basis, std-form {m}x{fp.n} with |N|={nN}" if dual else
+                                f"random dense LP m={m} n={n} (seed {args.seed}), primal simplex phase 1, "
+                                f"std-form {m}x{fp.n} with |N|={nN}"), "refactors_in_window": int(refactors),
                    "inverse_residual_after": resid,
                    "parallelism": ("single GPU" if world == 1 else
                                    f"column-block pricing sharded over {world} GPUs, 1 all-gather/iteration")},

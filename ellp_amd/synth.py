@@ -78,3 +78,35 @@ def primal_phase2_from(flat, x, B, N, Nb):
     out.update(c=c, kind=kind, x=np.array(x, copy=True), B=np.array(B, copy=True),
                N=np.array(N, copy=True), Nb=np.array(Nb, copy=True))
     return out
+
+
+def covering_lp(seed, m, n):
+    """Covering variant of the family for the DUAL loop: min c.x, c > 0, A x >= b, x >= 0 with the
+    same A and b = A x0 (> 0) and c_j = +(0.1 + u).  Returns A (Fortran order), b, c."""
+    A, b, c = dense_lp(seed, m, n)
+    return A, b, -c
+
+
+def dual_start_flat(seed, m, n):
+    """StandardForm + DualFeasiblePoint for covering_lp, built directly: rows `>=` get slack
+    coefficient -1, row i's slack in column n+m-1-i (standard_form.rs:115-136).  The slack basis is
+    dual feasible (y = 0, d = c >= 0) and primal infeasible (s = -b < 0), so
+    DualSimplexSolver::solve_with_initial (dual_simplex_solver.rs:110) starts pivoting at once —
+    this is what dual phase 2 looks like, without the reference's phase-1 detour (whose
+    first-infeasible leaving rule needs ~20x more pivots per doubling of m)."""
+    A, b, c = covering_lp(seed, m, n)
+    ncols = n + m
+    Af = np.zeros((m, ncols), dtype=np.float64, order="F")
+    Af[:, :n] = A
+    idx = np.arange(m)
+    Af[idx, n + m - 1 - idx] = -1.0
+    cc = np.zeros(ncols)
+    cc[:n] = c
+    x = np.zeros(ncols)
+    x[n + m - 1 - idx] = -b  # A_B = -I (permuted): s = -b
+    B = (n + m - 1 - idx).astype(np.int64)
+    return dict(
+        m=m, n=ncols, n_c=ncols, A=Af.reshape(-1, order="F"), c=cc, b=b.copy(),
+        kind=np.full(ncols, 1, dtype=np.uint8), lb=np.zeros(ncols), ub=np.zeros(ncols), x=x,
+        B=B, N=np.arange(n, dtype=np.int64), Nb=np.zeros(n, dtype=np.uint8),
+        y=np.zeros(m), d=cc.copy(), c_struct=c, n_struct=n)

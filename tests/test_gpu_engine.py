@@ -216,3 +216,32 @@ def test_default_maintenance_period_full_solve():
     st, stats, msg = E.primal_solve_with_initial(fp2, E.default_opts(max_iter=None, refactor_period=250))
     assert st == E.OPTIMAL, msg
     assert abs(fp2.obj() - (-251.6515333670212)) < 1e-7  # independent HiGHS objective, 200 x 500
+
+
+@pytest.mark.parametrize("m,n", [(20, 50), (60, 150)])
+def test_dual_synthetic_start(m, n):
+    """BASELINE config 4's workload at test size: dual loop from the dual-feasible slack basis of
+    the covering LP, pivot for pivot against the oracle, optimum against HiGHS."""
+    from scipy.optimize import linprog
+    from ellp_amd import synth
+    E = _engine()
+    f = synth.dual_start_flat(20260301, m, n)
+
+    class V:
+        pass
+    ov = V()
+    for k, val in f.items():
+        setattr(ov, k, val.copy() if hasattr(val, "copy") else val)
+    ov.nB, ov.nN = len(f["B"]), len(f["N"])
+    st_o, it_o, msg_o = eo.dual_solve_with_initial(ov)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"], f["y"], f["d"])
+    st_g, stats, msg = E.dual_solve_with_initial(fp, E.default_opts(max_iter=None))
+    assert st_g == st_o == E.OPTIMAL, (msg, msg_o)
+    assert stats.iters == it_o
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-9 * (1 + np.abs(ov.x).max()))
+    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-9 * (1 + np.abs(ov.y).max()))
+    A, b, c = synth.covering_lp(20260301, m, n)
+    h = linprog(c, A_ub=-A, b_ub=-b, bounds=(0, None), method="highs")
+    assert abs(fp.obj() - h.fun) < 1e-8

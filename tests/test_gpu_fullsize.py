@@ -1,0 +1,119 @@
+"""Parity at BASELINE.json's full sizes (configs 3 and 4: m=2000, n=5000).
+
+The oracle re-factorises every iteration, so only a short window is affordable: from the same
+start, after W iterations, the engine's (B, N, x[, y, d]) must equal the oracle's — same
+pivots.  Beyond the window, size-independent invariants of the simplex loop are checked:
+A x = b is preserved by every pivot, the phase-1 objective never increases, the point stays
+within its bounds, and W A_B = I."""
+import numpy as np
+import pytest
+
+from oracle import ellp_oracle as eo
+
+pytestmark = pytest.mark.gpu
+
+M, N_STRUCT, SEED = 2000, 5000, 20260301
+
+
+def _view(f):
+    class V:
+        pass
+    v = V()
+    for k, val in f.items():
+        setattr(v, k, val.copy() if hasattr(val, "copy") else val)
+    v.nB, v.nN = len(f["B"]), len(f["N"])
+    return v
+
+
+@pytest.fixture(scope="module")
+def primal_flat():
+    from ellp_amd import synth
+    return synth.primal_phase1_flat(SEED, M, N_STRUCT)
+
+
+@pytest.fixture(scope="module")
+def dual_flat():
+    from ellp_amd import synth
+    return synth.dual_start_flat(SEED, M, N_STRUCT)
+
+
+def test_c3_primal_window_parity(primal_flat):
+    from ellp_amd import _engine as E
+    W = 40
+    f = primal_flat
+    ov = _view(f)
+    st_o, it_o, _ = eo.primal_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    st_g, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, msg
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_array_equal(fp.Nb, ov.Nb)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-9 * (1 + np.abs(ov.x).max()))
+
+
+def test_c4_dual_window_parity(dual_flat):
+    from ellp_amd import _engine as E
+    W = 40
+    f = dual_flat
+    ov = _view(f)
+    st_o, it_o, _ = eo.dual_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"], f["y"], f["d"])
+    st_g, stats, msg = E.dual_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, msg
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-9 * (1 + np.abs(ov.x).max()))
+    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-9 * (1 + np.abs(ov.y).max()))
+    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-9 * (1 + np.abs(ov.d).max()))
+
+
+def test_c3_primal_invariants_over_a_long_run(primal_flat):
+    """3000 iterations in slices: A x = b, objective non-increasing, bounds, W A_B = I."""
+    from ellp_amd import _engine as E
+    f = primal_flat
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    A = f["A"].reshape((f["n"], f["m"])).T
+    b = f["b"]
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+    prev_obj = fp.obj()
+    scale = 1.0 + np.abs(b).max()
+    for _ in range(6):
+        st, stats, msg = eng.run(500)
+        assert st == E.MAXITER, msg
+        eng.read_point()
+        assert np.max(np.abs(A @ fp.x - b)) < 1e-8 * scale          # every pivot keeps A x = b
+        assert fp.x.min() > -1e-8 * scale                            # all variables are Lower(0)
+        obj = fp.obj()
+        assert obj <= prev_obj + 1e-8 * scale                        # phase-1 objective never increases
+        prev_obj = obj
+        assert sorted(np.concatenate([fp.B, fp.N]).tolist()) == list(range(f["n"]))  # B u N is a partition
+    assert eng.inverse_residual() < 1e-10
+    eng.close()
+
+
+def test_c4_dual_invariants_over_a_long_run(dual_flat):
+    """Dual loop: dual feasibility of the nonbasics (d_j >= -eps at Lower), y consistent with d,
+    dual objective non-decreasing."""
+    from ellp_amd import _engine as E
+    f = dual_flat
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"], f["y"], f["d"])
+    A = f["A"].reshape((f["n"], f["m"])).T
+    eng = E.Engine(E.ENGINE_DUAL, fp, E.default_opts(max_iter=None))
+    prev = -np.inf
+    for _ in range(4):
+        st, stats, msg = eng.run(500)
+        assert st == E.MAXITER, msg
+        eng.read_point()
+        assert fp.d[fp.N].min() > -1e-8                               # nonbasics stay dual feasible
+        np.testing.assert_allclose(fp.d, f["c"] - A.T @ fp.y, rtol=0, atol=1e-8)   # d = c - A^T y
+        assert np.max(np.abs(fp.d[fp.B])) < 1e-8                     # basics have zero reduced cost
+        dual_obj = float(np.dot(f["b"], fp.y))                        # bounds are all Lower(0)
+        assert dual_obj >= prev - 1e-8
+        assert abs(dual_obj - stats.obj) < 1e-6 * (1 + abs(dual_obj))  # incremental obj (dual…:316) tracks it
+        prev = dual_obj
+    eng.close()
