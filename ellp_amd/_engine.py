@@ -20,7 +20,7 @@ ENGINE_PRIMAL, ENGINE_DUAL = 0, 1
 K_NAMES = ["price", "select", "ftran", "ratio", "update", "btran", "refactor", "dleave", "dprice",
            "dselect", "dupdate", "_"]
 K_COUNT = 12
-TAP_U, TAP_R, TAP_D, TAP_BINV, TAP_KEY, TAP_ALPHA = range(6)
+TAP_U, TAP_R, TAP_D, TAP_BINV, TAP_KEY, TAP_ALPHA, TAP_STATE = range(7)
 
 
 class Opts(C.Structure):

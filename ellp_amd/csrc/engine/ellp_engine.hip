@@ -53,6 +53,7 @@
 namespace {
 
 constexpr int ST_RUNNING = 100;
+constexpr int ST_NEED_MAINT = 101;  // internal: a tiny pivot was taken; refresh B^-1 before going on
 constexpr int WAVE = 64;
 
 struct DevState {
@@ -873,6 +874,7 @@ struct Update2Args {
     int rows_per_block;
     int update_u;
     int stage_lds;
+    double ill_tol;   // > 0: after a pivot with |alpha_r| < ill_tol * max|alpha| stop for maintenance
     double eps;
 };
 
@@ -1064,6 +1066,23 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
 
     // ---------------- block 0: bookkeeping
     const int64_t jq = st->s_jq;
+    // A pivot that is tiny next to the rest of its column makes the basis ill-conditioned for a
+    // while and leaves O(cond * eps) error in B^-1 that the eta updates then carry along, where
+    // the reference's per-iteration LU would forget it at once.  On small LPs (a refresh is a few
+    // tens of us) stop the batch after such a pivot; the host refreshes B^-1 now and once more
+    // after the following iteration.
+    bool tiny_pivot = false;
+    if (a.ill_tol > 0.0 && r >= 0) {
+        double amax = 0.0;
+        for (int64_t i = tid; i < m; i += 256) amax = fmax(amax, fabs(a.d[i]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmax(amax, __shfl_xor(amax, o));
+        __shared__ double s_amax[4];
+        if (lane == 0) s_amax[wave] = amax;
+        __syncthreads();
+        amax = fmax(fmax(s_amax[0], s_amax[1]), fmax(s_amax[2], s_amax[3]));
+        tiny_pivot = fabs(d_r) < a.ill_tol * amax;
+    }
     if (MODE == 0) {
         if (lambda > 0.0) {  // primal…:408-417
             for (int64_t i0 = tid; i0 < m; i0 += 4 * 256) {
@@ -1112,6 +1131,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->cur = cur ^ 1;
                 st->pivots += 1;
                 st->iters += 1;
+                if (tiny_pivot) st->status = ST_NEED_MAINT;
             }
         } else if (tid == 0) {  // primal…:223-231
             const int nbq = a.Nb[q];
@@ -1172,6 +1192,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         }
         __syncthreads();
         find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, m, tid, s_tmp, st);
+        if (tid == 0 && tiny_pivot && st->status == ST_RUNNING) st->status = ST_NEED_MAINT;
     }
 }
 
@@ -1342,7 +1363,9 @@ __global__ __launch_bounds__(1024) void k_ref_pick(RefArgs a) {
             }
         }
         const long long p = bi;
-        if (p < 0 || bv < a.eps || bv != bv) {
+        // primal: any |U_ii| < EPS is Err("A_B is not invertible") (primal…:175-179); the dual loop
+        // has no such guard — only an exactly zero pivot makes its lu.solve() fail (dual…:294)
+        if (p < 0 || bv != bv || bv == 0.0 || bv < a.eps) {
             st->status = ELLP_ERR_SINGULAR;
         } else {
             a.used[p] = 1;
@@ -1567,7 +1590,7 @@ struct ellp_engine {
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
-    uint64_t refreshes = 0;
+    uint64_t refreshes = 0, maint_requests = 0;
     double last_residual = 0.0;
     int64_t *B_index = nullptr, *N_index = nullptr, *perm = nullptr;
     uint8_t *kindv = nullptr, *Nb = nullptr, *dpos = nullptr;
@@ -1579,6 +1602,8 @@ struct ellp_engine {
     int64_t seg = 0;
     hipStream_t own_stream = nullptr;
     bool need_dleave = true;
+    double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
+    int maint_chain = 0;   // > 0: refresh again after the next single iteration
     // launch geometry
     int cpb = 1, nblocks = 1, priceT = 1;
     int upd_rows = 4, upd_blocks = 1;
@@ -1731,6 +1756,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
+    a.ill_tol = e->ill_tol;
     const dim3 g(e->upd_blocks + 1), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
@@ -1751,7 +1777,8 @@ void launch_btran(ellp_engine *e) {
 
 void launch_refactor(ellp_engine *e) {
     Prof p(e, ELLP_K_REFACTOR);
-    RefArgs a{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows, e->eps};
+    RefArgs a{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows,
+              e->kind == ELLP_ENGINE_PRIMAL ? e->eps : 0.0};
     hipLaunchKernelGGL(k_ref_begin, dim3(1), dim3(1), 0, e->stream, a);
     hipLaunchKernelGGL(k_ref_init, dim3(1024), dim3(256), 0, e->stream, a);
     for (int64_t k = 0; k < e->m; ++k) {
@@ -1792,10 +1819,35 @@ double launch_refresh(ellp_engine *e) {
     return res;
 }
 
+// Default maintenance period: a refresh costs ~2*(2 m^3)/25 TFLOP/s + one host sync, an iteration
+// ~(8 ld |N| + 24 m ld)/5 TB/s + 15 us; clamp(m/2, 64, 1000) keeps the overhead at a few percent
+// at every size while small (often degenerate) LPs, whose refresh is nearly free, stay close to
+// the reference's always-fresh factorisation.
+int64_t default_period(const ellp_engine *e) {
+    int64_t p = e->m / 2;
+    if (p < 64) p = 64;
+    if (p > 1000) p = 1000;
+    return p;
+}
+
 // periodic maintenance of B^-1: Newton-Schulz refresh, full rebuild only if that is not safe
 void maintain_inverse(ellp_engine *e) {
     const double res = launch_refresh(e);
     if (!(res >= 0.0 && res < 1e-4)) launch_refactor(e);
+}
+
+// After a status read-back: if a kernel asked for maintenance, do it, re-arm the loop and report
+// true (the caller keeps going).  The flagged iteration committed nothing, so it is simply redone.
+bool service_maintenance_request(ellp_engine *e) {
+    if (e->h_st->status != ST_NEED_MAINT) return false;
+    maintain_inverse(e);
+    e->maint_chain = 1;
+    const int32_t running = ST_RUNNING;
+    (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    e->h_st->status = ST_RUNNING;
+    e->maint_requests += 1;
+    return true;
 }
 
 void launch_primal_iteration(ellp_engine *e) {
@@ -2034,6 +2086,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         }
         e->ftran_lds = sizeof(double) * (size_t)e->nblocks + 16;
         e->refactor_period = e->opts.refactor_period > 0 ? e->opts.refactor_period : 0;
+        e->ill_tol = (m <= 512) ? 1e-3 : 0.0;
     }
 
     ECHK(dmalloc(e, &e->A_B, (size_t)(ld * m)));
@@ -2190,7 +2243,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : (e->m <= 256 ? 64 : 16);
     int64_t period = e->refactor_period;
-    if (period <= 0) period = 1000;  // default; see DESIGN.md §numerics
+    if (period <= 0) period = default_period(e);
     ellp_status result = ELLP_MAXITER;
     if (e->nN == 0) {
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
@@ -2211,8 +2264,10 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             result = status_message(*e->h_st, errbuf, errlen);
             remaining = 0;
         }
+        const uint64_t iters0 = e->h_st->iters;
         while (remaining > 0) {
-            const uint64_t batch = remaining < poll ? remaining : poll;
+            const bool chained = e->maint_chain > 0;
+            const uint64_t batch = chained ? 1 : (remaining < poll ? remaining : poll);
             for (uint64_t it = 0; it < batch; ++it) {
                 if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
                 if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
@@ -2222,7 +2277,12 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             HIPCHK(hipStreamSynchronize(e->stream));
             HIPCHK(hipGetLastError());
             prof_collect(e);
-            remaining -= batch;
+            // iterations that really ran (a maintenance request voids the rest of its batch)
+            const uint64_t done = e->h_st->iters - iters0;
+            remaining = done < max_iters ? max_iters - done : 0;
+            if (chained) e->maint_chain = 0;
+            if (service_maintenance_request(e)) continue;
+            if (chained && e->h_st->status == ST_RUNNING) maintain_inverse(e);  // the follow-up refresh
             if (e->h_st->status != ST_RUNNING) {
                 result = status_message(*e->h_st, errbuf, errlen);
                 break;
@@ -2281,6 +2341,17 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
         src = e->X + 2 * e->nbs;
         count = e->nN;
         break;
+    case ELLP_TAP_STATE: {
+        if (cap < 12) return ELLP_ERR_ARG;
+        if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess)
+            return ELLP_ERR_DEVICE;
+        const DevState &h = *e->h_st;
+        const double v[12] = {(double)h.status, (double)h.cur, (double)h.s_q, (double)h.s_r, h.s_theta_d, h.s_delta,
+                              (double)h.lr, h.ldelta, (double)h.iters, (double)h.pivots, h.lambda, h.s_rq};
+        for (int k = 0; k < 12; ++k) dst[k] = v[k];
+        return 12;
+    }
     case ELLP_TAP_BINV: {
         // row-major m x m without the padding
         count = e->m * e->m;
@@ -2366,7 +2437,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
     HIPCHK(hipSetDevice(e->device));
     if (e->nN == 0) return ELLP_OPTIMAL;
     if (phase == 0) {
-        int64_t period = e->refactor_period > 0 ? e->refactor_period : 1000;
+        int64_t period = e->refactor_period > 0 ? e->refactor_period : default_period(e);
         if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
         if (e->kind == ELLP_ENGINE_PRIMAL) {
             const bool full_btran =
@@ -2416,12 +2487,13 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
     HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     prof_collect(e);
+    (void)service_maintenance_request(e);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->iters = e->h_st->iters;
         stats->pivots = e->h_st->pivots;
         stats->bound_flips = e->h_st->flips;
-        stats->refactors = e->refactors;
+        stats->refactors = e->refactors + e->refreshes;
         stats->obj = e->h_st->obj;
         stats->t_setup_s = e->t_setup;
         for (int k = 0; k < ELLP_K_COUNT; ++k) {

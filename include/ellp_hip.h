@@ -190,7 +190,7 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
 enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,
-       ELLP_TAP_ALPHA = 5 };
+       ELLP_TAP_ALPHA = 5, ELLP_TAP_STATE = 6 /* 12 doubles: status,cur,s_q,s_r,theta_d,delta,lr,ldelta,iters,pivots,lambda,rq */ };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
 /* One Newton-Schulz step W <- W + W (I - A_B W) on the resident inverse (two f64 GEMMs); this
