@@ -77,12 +77,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+    # test hooks (dry runs on a 1-GPU box): ELLP_BENCH_BACKEND=gloo, ELLP_BENCH_DEVICE=0
+    backend = os.environ.get("ELLP_BENCH_BACKEND", "nccl")
+    if "ELLP_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["ELLP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from ellp_amd import _engine as E
     from ellp_amd import synth
@@ -120,7 +127,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     steps_done = stats.iters - it0
