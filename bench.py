@@ -152,6 +152,11 @@ def main():
     # N>1: the ranks cooperate on ONE pivot stream (pricing sharded, the rest replicated)
     pivots_per_s = args.steps / dt
     price_bytes = 8.0 * ld * nN
+    if world > 1:  # each rank prices only its block of the nonbasic positions
+        from ellp_amd.dist import shard_ranges
+        cpb = max(1, min(64, (nN + 1023) // 1024))
+        a0, a1 = shard_ranges(nN, cpb, world)[0]
+        price_bytes = 8.0 * ld * (a1 - a0)
     # HBM traffic of the pricing kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE, gfx950 x2 read correction) — only valid for the workload it was measured on
     traffic = None

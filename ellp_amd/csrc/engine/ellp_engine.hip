@@ -2434,6 +2434,11 @@ ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream) {
 
 ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
+    if (phase == 2) {  // second half of this iteration + first half of the next, one host call
+        const ellp_status s1 = ellp_engine_step(e, 1, errbuf, errlen);
+        if (s1 != ELLP_OPTIMAL) return s1;
+        return ellp_engine_step(e, 0, errbuf, errlen);
+    }
     HIPCHK(hipSetDevice(e->device));
     if (e->nN == 0) return ELLP_OPTIMAL;
     if (phase == 0) {

@@ -38,6 +38,8 @@ def all_gather_segments(full, mine, rank, world, group=None):
         return
     backend = dist.get_backend(group)
     if backend == "nccl":
+        # `mine` may be the rank's own slice of `full` (in-place all-gather, supported by NCCL/RCCL
+        # when sendbuff == recvbuff + rank * count)
         dist.all_gather_into_tensor(full, mine, group=group)
         return
     src = mine.detach().cpu().contiguous()
@@ -76,8 +78,12 @@ class ShardedEngine:
         """Must be called with self.stream current (run() does)."""
         if self.world == 1:
             return
-        self.send.copy_(self.full[self.rank * self.seg:(self.rank + 1) * self.seg])
-        all_gather_segments(self.full, self.send, self.rank, self.world, self.group)
+        mine = self.full[self.rank * self.seg:(self.rank + 1) * self.seg]
+        if self.dist.get_backend(self.group) == "nccl":
+            all_gather_segments(self.full, mine, self.rank, self.world, self.group)  # in place
+        else:
+            self.send.copy_(mine)
+            all_gather_segments(self.full, self.send, self.rank, self.world, self.group)
 
     def run(self, max_iters, poll_interval=16):
         """Up to `max_iters` further iterations; returns (status, Stats, message) like Engine.run."""
@@ -86,10 +92,13 @@ class ShardedEngine:
             status, stats, msg = self.eng.poll()
             while status == E.MAXITER and done < max_iters:
                 batch = min(poll_interval, max_iters - done)
-                for _ in range(batch):
-                    self.eng.step(0)
+                # one host call + one collective per iteration: step(2) = rest of iteration k and
+                # the pricing of iteration k+1 (the last one prices ahead; a later step(0) simply
+                # prices again from the same state)
+                self.eng.step(0)
+                for k in range(batch):
                     self.exchange()
-                    self.eng.step(1)
+                    self.eng.step(2 if k + 1 < batch else 1)
                 done += batch
                 status, stats, msg = self.eng.poll()
         return status, stats, msg

@@ -176,7 +176,8 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index,
  *                 allocate it
  *   exchange_info: device pointer of the buffer, doubles per segment, rank, world
  *   set_stream  : run the engine's launches on a caller-owned HIP stream (NULL = its own)
- *   step        : enqueue one half-iteration (never blocks)
+ *   step        : enqueue one half-iteration (never blocks): 0 = pricing, 1 = the rest,
+ *                 2 = the rest of this iteration followed by the next iteration's pricing
  *   poll        : copy the status word back; ELLP_MAXITER = still running
  */
 int64_t ellp_engine_segment_doubles(ellp_engine *e, int world);
