@@ -154,7 +154,8 @@ def main():
     price_bytes = 8.0 * ld * nN
     if world > 1:  # each rank prices only its block of the nonbasic positions
         from ellp_amd.dist import shard_ranges
-        cpb = max(1, min(64, (nN + 1023) // 1024))
+        nt = 8.0 * ld * nN > 160e6
+        cpb = max(1, min(64, (nN + 2047) // 2048 if nt else (nN + 1023) // 1024))
         a0, a1 = shard_ranges(nN, cpb, world)[0]
         price_bytes = 8.0 * ld * (a1 - a0)
     # HBM traffic of the pricing kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
