@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     int buf = 0;
     for (int64_t j = j0; j < j1; j += 4, buf ^= 1) {
         const int ncol = (int)((j1 - j) < 4 ? (j1 - j) : 4);
+        // epilogue inputs of the (up to 4) column-owner threads: issued before the column stream
+        // so that their dependent gathers (N_index -> d) are back when the dot products are
+        int nb_pre = 0;
+        double cd_pre = 0.0;  // primal: c_N[j] ; dual: d[N_index[j]]
+        {
+            const int64_t jo = j + (tid < ncol ? tid : 0);
+            nb_pre = a.Nb[jo];
+            cd_pre = (MODE == 0) ? a.c_N[jo] : a.dd[a.N_index[jo]];
+        }
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         const double2 *col[4];
 #pragma unroll
@@ -234,9 +243,9 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
             const double dot =
                 ((s_part[buf][0][k] + s_part[buf][1][k]) + s_part[buf][2][k]) + s_part[buf][3][k];
             const int64_t jj = j + k;
-            const int nb = a.Nb[jj];
+            const int nb = nb_pre;
             if (MODE == 0) {
-                const double rj = a.c_N[jj] - dot;
+                const double rj = cd_pre - dot;
                 double key = -INFINITY;
                 if (rj != rj) {
                     st->nan_flag = 1;
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
                 else if (nb == ELLP_NB_UPPER) keep = al < -a.eps;
                 else keep = true;
                 if (keep) {
-                    const double ratio = a.dd[a.N_index[jj]] / al;
+                    const double ratio = cd_pre / al;
                     if (ratio != ratio) st->nan_flag = 1;
                     if (bestpos < 0 || ratio < best) {  // strict '<' keeps the FIRST minimum
                         best = ratio;
@@ -912,12 +921,15 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     int64_t r;
     double lambda = 0.0;
     int side = 0;
-    // block 0 does the bookkeeping only; blocks 1.. stream rows_per_block (<= 4) rows each
-    const int64_t row0 = ((int64_t)blockIdx.x - 1) * a.rows_per_block;
+    // the first NBK blocks do bookkeeping only (primal 1; dual 2: block 0 the O(|N|) reduced-cost
+    // update, block 1 the rest); blocks NBK.. stream rows_per_block (<= 4) rows each
+    constexpr int NBK = MODE == 0 ? 1 : 2;
+    const bool row_block = blockIdx.x >= NBK;
+    const int64_t row0 = ((int64_t)blockIdx.x - NBK) * a.rows_per_block;
     double dv[UPD_ROWS];
 #pragma unroll
     for (int k = 0; k < UPD_ROWS; ++k)
-        dv[k] = (blockIdx.x > 0 && k < a.rows_per_block && row0 + k < m) ? a.d[row0 + k] : 0.0;
+        dv[k] = (row_block && k < a.rows_per_block && row0 + k < m) ? a.d[row0 + k] : 0.0;
     constexpr int NRR = NR > 0 ? NR : 1;
     double2 wreg[UPD_ROWS][NRR];
     const int64_t halfw = a.ld >> 1;
@@ -957,7 +969,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
 #pragma unroll
                 for (int k = 0; k < UPD_ROWS; ++k) {
                     const int64_t i = row0 + k;
-                    const bool ok = blockIdx.x > 0 && k < a.rows_per_block && i < m;
+                    const bool ok = row_block && k < a.rows_per_block && i < m;
                     const double2 *srow = reinterpret_cast<const double2 *>(src + (ok ? i : 0) * a.ld);
 #pragma unroll
                     for (int u = 0; u < NR; ++u) {
@@ -1025,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
 #pragma unroll
             for (int k = 0; k < UPD_ROWS; ++k) {
                 const int64_t i = row0 + k;
-                const bool ok = blockIdx.x > 0 && k < a.rows_per_block && i < m;
+                const bool ok = row_block && k < a.rows_per_block && i < m;
                 const double2 *srow = reinterpret_cast<const double2 *>(src + (ok ? i : 0) * a.ld);
 #pragma unroll
                 for (int u = 0; u < NR; ++u) {
@@ -1042,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     if (r >= 0) {
         d_r = a.d[r];
         alpha_r = (MODE == 0 && at_lower) ? -d_r : d_r;
-        if (blockIdx.x > 0) {
+        if (row_block) {
             if (NR > 0) {
                 const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
                 double2 pr[NRR];
@@ -1077,9 +1089,9 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             }
         }
     }
-    if (blockIdx.x != 0) return;
+    if (row_block) return;
 
-    // ---------------- block 0: bookkeeping
+    // ---------------- bookkeeping block(s)
     const int64_t jq = st->s_jq;
     // A pivot that is tiny next to the rest of its column makes the basis ill-conditioned for a
     // while and leaves O(cond * eps) error in B^-1 that the eta updates then carry along, where
@@ -1166,6 +1178,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         const int64_t leaving_var = a.B_index[r];
         const double theta_p = delta / d_r;
         const double *rho = src + r * a.ld;
+        if (blockIdx.x == 0) {  // block 0: d[N_j] -= theta_d * alpha_j for every nonbasic j != q
         for (int64_t j0 = tid; j0 < a.nN; j0 += 4 * 256) {
             int64_t v[4];
             double al[4], dv[4];
@@ -1182,6 +1195,9 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             for (int k = 0; k < 4; ++k)
                 if (v[k] >= 0) a.dd[v[k]] = dv[k] - theta_d * al[k];
         }
+        return;
+        }
+        // block 1: y, x, the swap, the scalars and the next leaving row
         for (int64_t i = tid; i < m; i += 256) {
             a.y[i] = a.y[i] + theta_d * rho[i];
             const int64_t bi = a.B_index[i];
@@ -1808,7 +1824,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
-    const dim3 g(e->upd_blocks + 1), b(256);
+    const dim3 g(e->upd_blocks + (MODE == 0 ? 1 : 2)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
     if (nr <= 1) hipLaunchKernelGGL((k_update2<MODE, 1>), g, b, lds, e->stream, a);
