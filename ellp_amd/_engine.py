@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libellp_hip.so")
+LIB_PATH = os.environ.get("ELLP_HIP_LIB") or os.path.join(_HERE, "libellp_hip.so")  # override: dev builds only
 
 OPTIMAL, INFEASIBLE, UNBOUNDED, MAXITER = 0, 1, 2, 3
 ERR_BAD_DIMS, ERR_SINGULAR, ERR_NAN, ERR_DEVICE, ERR_ARG, ERR_PANIC = -1, -2, -3, -4, -5, -6
