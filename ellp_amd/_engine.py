@@ -18,7 +18,7 @@ STATUS_NAME = {0: "optimal", 1: "infeasible", 2: "unbounded", 3: "maxiter", -1: 
 MAX_ITER_NONE = 2**64 - 1
 ENGINE_PRIMAL, ENGINE_DUAL = 0, 1
 K_NAMES = ["price", "select", "ftran", "ratio", "update", "btran", "refactor", "dleave", "dprice",
-           "dselect", "dupdate", "_"]
+           "dselect", "dupdate", "event_cost"]
 K_COUNT = 12
 TAP_U, TAP_R, TAP_D, TAP_BINV, TAP_KEY, TAP_ALPHA, TAP_STATE = range(7)
 

@@ -73,16 +73,17 @@ class ShardedEngine:
         self.stream = torch.cuda.Stream()
         assert self.stream.cuda_stream != 0
         self.eng.set_stream(self.stream.cuda_stream)
+        self.mine = self.full[self.rank * seg:(self.rank + 1) * seg]  # this rank's slice (a view)
+        self.nccl = self.world > 1 and dist.get_backend(group) == "nccl"
 
     def exchange(self):
         """Must be called with self.stream current (run() does)."""
         if self.world == 1:
             return
-        mine = self.full[self.rank * self.seg:(self.rank + 1) * self.seg]
-        if self.dist.get_backend(self.group) == "nccl":
-            all_gather_segments(self.full, mine, self.rank, self.world, self.group)  # in place
+        if self.nccl:  # in place: sendbuff == recvbuff + rank * count
+            self.dist.all_gather_into_tensor(self.full, self.mine, group=self.group)
         else:
-            self.send.copy_(mine)
+            self.send.copy_(self.mine)
             all_gather_segments(self.full, self.send, self.rank, self.world, self.group)
 
     def run(self, max_iters, poll_interval=16):

@@ -84,6 +84,7 @@ enum {
     ELLP_K_DPRICE = 8,  /* alpha = A_N^T rho (+ ratios)          dual…:255-278 */
     ELLP_K_DSELECT = 9, /* dual ratio argmin                     dual…:279-289 */
     ELLP_K_DUPDATE = 10,/* d, y, x updates + swap                dual…:296-333 */
+    ELLP_K_EVENT_COST = 11, /* not a kernel: kernel_ms[11] = the event-bracket cost subtracted per launch */
     ELLP_K_COUNT = 12
 };
 

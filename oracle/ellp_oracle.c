@@ -1193,6 +1193,309 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
     return status;
 }
 
+/* ------------------------------------------------------------------ primal loop, explicit B^-1
+ * NOT the reference's linear algebra: the same pivoting rules as the loop above
+ * (primal_simplex_solver.rs:253-292 entering fold, :305-400 ratio test, :205-232 swap), but
+ * B^-1 is kept explicitly and updated by the rank-1 (eta) formula, as the HIP engine does,
+ * and the O(m|N|) / O(m^2) passes run on `threads` OpenMP threads.  Two uses, both test
+ * infrastructure: (1) the "same algorithm on the host cores" CPU baseline that bench.py reports
+ * next to the reference-algorithm baseline; (2) pivot-sequence parity with
+ * the engine over windows of thousands of pivots at full size, where the LU-per-iteration loop
+ * would take hours.  It is itself checked against the loop above (tests/test_oracle_binv.py).
+ * refresh > 0: B^-1 is recomputed from an LU of A_B every `refresh` basis changes. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include <time.h>
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* four independent partial sums: the order of additions differs from the reference loop's
+ * single chain (last-bit differences only), and the adds no longer wait on each other */
+static double dot4(const double *a, const double *v, int64_t n) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        s0 += a[i] * v[i];
+        s1 += a[i + 1] * v[i + 1];
+        s2 += a[i + 2] * v[i + 2];
+        s3 += a[i + 3] * v[i + 3];
+    }
+    for (; i < n; ++i) s0 += a[i] * v[i];
+    return (s0 + s1) + (s2 + s3);
+}
+
+/* W (row-major m x m) = A_B^-1 ; 0 if A_B fails the reference's singularity guard (:175-179) */
+static int binv_from_lu(const double *A_B, int64_t m, double *W, int threads) {
+    lu_t f;
+    lu_factor(&f, A_B, m, m);
+    int ok = !lu_small_diag(&f);
+    if (ok) {
+        int bad = 0;
+        (void)threads;
+#pragma omp parallel num_threads(threads)
+        {
+            double *e = (double *)xmalloc(sizeof(double) * (size_t)m);
+#pragma omp for schedule(static)
+            for (int64_t k = 0; k < m; ++k) {
+                memset(e, 0, sizeof(double) * (size_t)m);
+                e[k] = 1.0;
+                if (!lu_solve(&f, e)) {
+#pragma omp atomic write
+                    bad = 1;
+                }
+                for (int64_t i = 0; i < m; ++i) W[i * m + k] = e[i];
+            }
+            free(e);
+        }
+        if (bad) ok = 0;
+    }
+    lu_free(&f);
+    return ok;
+}
+
+int eo_primal_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,
+                                      const double *c, const double *b, const uint8_t *kind,
+                                      const double *lb, const double *ub, double *x, int64_t *B,
+                                      int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
+                                      uint64_t max_iter, uint64_t *iters_out, int threads,
+                                      int refresh, double *loop_seconds, char *err, size_t errlen) {
+    (void)b;
+    (void)n_c;
+    if (iters_out) *iters_out = 0;
+    if (loop_seconds) *loop_seconds = 0.0;
+    if (m <= 0 || nB != m || n < m || nN != n - m) {
+        set_err(err, errlen, "bad dimensions");
+        return EO_ERR_BAD_DIMS;
+    }
+    if (nN == 0) return EO_OPTIMAL;
+    if (threads < 1) threads = 1;
+
+    double *A_B = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *c_B = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *A_N = (double *)xmalloc(sizeof(double) * (size_t)(m * nN));
+    double *c_N = (double *)xmalloc(sizeof(double) * (size_t)nN);
+    for (int64_t i = 0; i < m; ++i) {
+        memcpy(A_B + i * m, A + B[i] * m, sizeof(double) * (size_t)m);
+        c_B[i] = c[B[i]];
+    }
+    for (int64_t j = 0; j < nN; ++j) {
+        memcpy(A_N + j * m, A + N[j] * m, sizeof(double) * (size_t)m);
+        c_N[j] = c[N[j]];
+    }
+    double *W = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *u = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *r = (double *)xmalloc(sizeof(double) * (size_t)nN);
+    double *d = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *rho = (double *)xmalloc(sizeof(double) * (size_t)m);
+
+    int status = EO_ERR_PANIC;
+    uint64_t iter = 1, entered = 0, since_refresh = 0, since_btran = 0;
+    int u_valid = 0;
+    if (!binv_from_lu(A_B, m, W, threads)) {
+        set_err(err, errlen, "invalid B, A_B is not invertible");
+        status = EO_ERR_SINGULAR;
+        goto done;
+    }
+    const double t0 = now_seconds();
+    for (;;) {
+        if (iter > max_iter) {
+            status = EO_MAXITER;
+            break;
+        }
+        iter += 1;
+        entered += 1;
+        if (refresh > 0 && since_refresh >= (uint64_t)refresh) {
+            if (!binv_from_lu(A_B, m, W, threads)) {
+                set_err(err, errlen, "invalid B, A_B is not invertible");
+                status = EO_ERR_SINGULAR;
+                break;
+            }
+            since_refresh = 0;
+            u_valid = 0;
+        }
+        if (!u_valid || since_btran >= 32) { /* u = B^-T c_B in full */
+#pragma omp parallel for schedule(static) num_threads(threads)
+            for (int64_t k = 0; k < m; ++k) {
+                double acc = 0.0;
+                for (int64_t i = 0; i < m; ++i) acc += c_B[i] * W[i * m + k];
+                u[k] = acc;
+            }
+            u_valid = 1;
+            since_btran = 0;
+        }
+        /* :189 pricing */
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int64_t j = 0; j < nN; ++j) {
+            r[j] = c_N[j] - dot4(A_N + j * m, u, m);
+        }
+        /* entering: the sequential max_by fold :253-287 */
+        int have = 0;
+        double r1 = 0.0;
+        int64_t q = -1;
+        for (int64_t j = 0; j < nN; ++j) {
+            double rj = r[j];
+            if (rj != rj) {
+                set_err(err, errlen, "NaN detected");
+                status = EO_ERR_NAN;
+                goto timed_done;
+            }
+            if (fabs(rj) < EPS) continue;
+            double key;
+            int pos = rj > 0.0;
+            if (pos && Nb[j] == EO_NB_UPPER) key = rj;
+            else if (!pos && Nb[j] == EO_NB_LOWER) key = -rj;
+            else if (Nb[j] == EO_NB_FREE) key = fabs(rj);
+            else continue;
+            if (!have) {
+                have = 1;
+                r1 = key;
+                q = j;
+                continue;
+            }
+            int acc_greater = (fabs(r1 - key) >= EPS) ? (r1 > key) : (N[q] > N[j]);
+            if (!acc_greater) {
+                r1 = key;
+                q = j;
+            }
+        }
+        if (!have) {
+            status = EO_OPTIMAL;
+            break;
+        }
+        const int64_t jq = N[q];
+        const int at_lower = (Nb[q] == EO_NB_LOWER);
+        /* FTRAN d = +-B^-1 a_q */
+        {
+            const double *aq = A_N + q * m;
+            const double sg = at_lower ? -1.0 : 1.0;
+#pragma omp parallel for schedule(static) num_threads(threads)
+            for (int64_t i = 0; i < m; ++i) {
+                d[i] = sg * dot4(W + i * m, aq, m);
+            }
+        }
+        double lambda;
+        switch (kind[jq]) {
+        case EO_TWOSIDED: lambda = ub[jq] - lb[jq]; break;
+        case EO_FIXED: lambda = 0.0; break;
+        default: lambda = INFINITY; break;
+        }
+        int64_t new_basic = -1;
+        int new_side = EO_NB_LOWER;
+        int have_nbi = 0;
+        int64_t nbi = 0;
+        for (int64_t i = 0; i < m; ++i) { /* :320-400 */
+            double di = d[i];
+            if (fabs(di) < EPS) continue;
+            const int64_t bi = B[i];
+            double xi = x[bi];
+            double li;
+            switch (kind[bi]) {
+            case EO_FREE: li = INFINITY; break;
+            case EO_LOWER:
+                if (di > 0.0) li = INFINITY;
+                else if (xi > lb[bi]) li = (lb[bi] - xi) / di;
+                else li = 0.0;
+                break;
+            case EO_UPPER:
+                if (di > 0.0) li = (xi < ub[bi]) ? (ub[bi] - xi) / di : 0.0;
+                else li = INFINITY;
+                break;
+            case EO_TWOSIDED:
+                if (di > 0.0) li = (xi < ub[bi]) ? (ub[bi] - xi) / di : 0.0;
+                else if (xi < lb[bi]) li = (lb[bi] - xi) / di; /* quirk Q1 :359 */
+                else li = 0.0;
+                break;
+            default: li = 0.0; break;
+            }
+            if (li < lambda - EPS) {
+                lambda = li;
+                new_basic = i;
+                new_side = (di > 0.0) ? EO_NB_UPPER : EO_NB_LOWER;
+            } else if (fabs(li - lambda) < EPS) {
+                if (!have_nbi || bi < nbi) {
+                    have_nbi = 1;
+                    nbi = bi;
+                    lambda = li;
+                    new_basic = i;
+                    new_side = (di > 0.0) ? EO_NB_UPPER : EO_NB_LOWER;
+                }
+            }
+        }
+        if (!(lambda >= 0.0)) {
+            set_err(err, errlen, "assertion failed: lambda >= 0.");
+            status = EO_ERR_PANIC;
+            break;
+        }
+        if (isinf(lambda)) {
+            status = EO_UNBOUNDED;
+            break;
+        }
+        if (lambda > 0.0) {
+            for (int64_t i = 0; i < m; ++i) x[B[i]] += lambda * d[i];
+            if (at_lower) x[jq] += lambda;
+            else x[jq] -= lambda;
+        }
+        if (g_trace)
+            g_trace(g_trace_user, entered, q, new_basic, jq, new_basic >= 0 ? B[new_basic] : -1);
+        if (new_basic >= 0) {
+            const int64_t rr = new_basic;
+            const double d_r = d[rr];
+            const double alpha_r = at_lower ? -d_r : d_r;
+            memcpy(rho, W + rr * m, sizeof(double) * (size_t)m);
+            { /* u += (r_q / alpha_r) * row_r(B^-1) */
+                const double cf = r[q] / alpha_r;
+                for (int64_t k = 0; k < m; ++k) u[k] = cf * rho[k] + u[k];
+                since_btran += 1;
+            }
+            /* B^-1 <- E B^-1 : row_i -= (d_i/d_r) row_r ; row_r /= alpha_r */
+#pragma omp parallel for schedule(static) num_threads(threads)
+            for (int64_t i = 0; i < m; ++i) {
+                double *wi = W + i * m;
+                if (i == rr) {
+                    for (int64_t k = 0; k < m; ++k) wi[k] = rho[k] / alpha_r;
+                } else {
+                    const double f = -(d[i] / d_r);
+                    if (f != 0.0)
+                        for (int64_t k = 0; k < m; ++k) wi[k] = f * rho[k] + wi[k];
+                }
+            }
+            int64_t t = B[rr];
+            B[rr] = N[q];
+            N[q] = t;
+            double *cn = A_N + q * m, *cb = A_B + rr * m;
+            for (int64_t i = 0; i < m; ++i) {
+                double tt = cn[i];
+                cn[i] = cb[i];
+                cb[i] = tt;
+            }
+            double tc = c_N[q];
+            c_N[q] = c_B[rr];
+            c_B[rr] = tc;
+            Nb[q] = (uint8_t)new_side;
+            since_refresh += 1;
+        } else {
+            if (Nb[q] == EO_NB_LOWER) Nb[q] = EO_NB_UPPER;
+            else if (Nb[q] == EO_NB_UPPER) Nb[q] = EO_NB_LOWER;
+            else {
+                set_err(err, errlen, "pivot should have been unbounded");
+                status = EO_ERR_PANIC;
+                break;
+            }
+        }
+    }
+timed_done:
+    if (loop_seconds) *loop_seconds = now_seconds() - t0;
+done:
+    if (iters_out) *iters_out = entered;
+    free(A_B); free(c_B); free(A_N); free(c_N); free(W); free(u); free(r); free(d); free(rho);
+    return status;
+}
+
 /* ------------------------------------------------------------------ dual hot loop
  * dual_simplex_solver.rs:110-335 */
 int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,

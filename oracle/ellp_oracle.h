@@ -123,6 +123,21 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
                                double *d, uint64_t max_iter, uint64_t *iters, char *err,
                                size_t errlen);
 
+/*
+ * Same pivoting rules as eo_primal_solve_with_initial, but B^-1 is kept explicitly and updated
+ * by the eta formula (what the HIP engine does) and the big passes run on `threads` OpenMP
+ * threads.  The "same algorithm on the host cores" baseline of bench.py and the checker for
+ * long pivot windows at full size; checked against the LU-per-iteration loop in
+ * tests/test_oracle_binv.py.  refresh > 0: B^-1 is rebuilt from an LU every `refresh` basis
+ * changes.  *loop_seconds = time spent in the loop (the initial inverse excluded).
+ */
+int eo_primal_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,
+                                      const double *c, const double *b, const uint8_t *kind,
+                                      const double *lb, const double *ub, double *x, int64_t *B,
+                                      int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
+                                      uint64_t max_iter, uint64_t *iters, int threads, int refresh,
+                                      double *loop_seconds, char *err, size_t errlen);
+
 /* Optional per-iteration trace for pivot-sequence parity (entering position, leaving
  * position or -1, objective). Set to NULL to disable.  Not thread-safe (test use only). */
 typedef void (*eo_trace_fn)(void *user, uint64_t iter, int64_t entering_pos,

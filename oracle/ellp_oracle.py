@@ -64,6 +64,7 @@ def lib():
     if _lib is not None:
         return _lib
     build()
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP threads sleep instead of spinning
     L = C.CDLL(_LIB_PATH)
     L.eo_problem_new.restype = C.c_void_p
     L.eo_problem_free.argtypes = [C.c_void_p]
@@ -98,6 +99,9 @@ def lib():
     L.eo_primal_solve_with_initial.argtypes = common + tail
     L.eo_dual_solve_with_initial.restype = C.c_int
     L.eo_dual_solve_with_initial.argtypes = common + [C.c_void_p, C.c_void_p] + tail
+    L.eo_primal_binv_solve_with_initial.restype = C.c_int
+    L.eo_primal_binv_solve_with_initial.argtypes = common + [
+        C.c_uint64, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
     L.eo_solve.restype = C.c_int
     L.eo_solve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(_Result)]
     L.eo_result_free.argtypes = [C.POINTER(_Result)]
@@ -284,6 +288,30 @@ def primal_solve_with_initial(ph, max_iter=MAX_ITER_NONE):
         _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
         max_iter, C.byref(it), err, 256)
     return st, it.value, err.value.decode()
+
+
+def host_threads():
+    """Threads for the OpenMP loops: the affinity mask, capped at 16 — a one-GPU box exposes all
+    of the host's CPUs (256) but grants a share of 16, and spinning OpenMP threads beyond the
+    share are far slower than none."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(16, n))
+
+
+def primal_binv_solve_with_initial(ph, max_iter=MAX_ITER_NONE, threads=None, refresh=0):
+    """The primal loop with the SAME pivoting rules but an explicitly maintained B^-1 (eta updates)
+    on `threads` OpenMP threads — the engine's algorithm on the host cores.  In place on a Phase
+    view.  Returns (status, iters, err, loop_seconds)."""
+    if threads is None:
+        threads = host_threads()
+    it = C.c_uint64(0)
+    secs = C.c_double(0.0)
+    err = C.create_string_buffer(256)
+    st = lib().eo_primal_binv_solve_with_initial(
+        ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
+        _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
+        max_iter, C.byref(it), int(threads), int(refresh), C.byref(secs), err, 256)
+    return st, it.value, err.value.decode(), secs.value
 
 
 def dual_solve_with_initial(ph, max_iter=MAX_ITER_NONE):

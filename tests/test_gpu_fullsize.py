@@ -53,6 +53,26 @@ def test_c3_primal_window_parity(primal_flat):
     np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-9 * (1 + np.abs(ov.x).max()))
 
 
+def test_c3_primal_long_window_parity(primal_flat):
+    """3000 pivots (500 on a slow host) at full size: the engine's basis equals that of the explicit-B^-1 CPU loop
+    (same pivot rules as the oracle, checked against it in tests/test_oracle_binv.py; the
+    LU-per-iteration loop itself would need ~40 minutes for this window)."""
+    from ellp_amd import _engine as E
+    f = primal_flat
+    _, it_p, _, secs_p = eo.primal_binv_solve_with_initial(_view(f), 40)  # probe the host's rate
+    W = 3000 if it_p / max(secs_p, 1e-9) > 100.0 else 500               # keep the CPU side under ~30 s
+    ov = _view(f)
+    st_o, it_o, msg_o, _ = eo.primal_binv_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    st_g, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, (msg, msg_o)
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_array_equal(fp.Nb, ov.Nb)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
+
+
 def test_c4_dual_window_parity(dual_flat):
     from ellp_amd import _engine as E
     W = 40
