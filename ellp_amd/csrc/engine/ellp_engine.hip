@@ -1657,6 +1657,8 @@ struct ellp_engine {
     int32_t *used = nullptr, *bidx = nullptr;
     DevState *st = nullptr;
     DevState *h_st = nullptr;  // pinned
+    DevState *h_look = nullptr;  // pinned, 2 slots: status read-backs of the look-ahead loop
+    hipEvent_t look_ev[2] = {nullptr, nullptr};
     // pricing shard (column-block sharding across ranks; world = 1 on a single GPU)
     int rank = 0, world = 1, nbs = 1;
     int64_t seg = 0;
@@ -2060,6 +2062,9 @@ void ellp_engine_destroy(ellp_engine *e) {
     e->stream = e->own_stream;
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_st) (void)hipHostFree(e->h_st);
+    if (e->h_look) (void)hipHostFree(e->h_look);
+    for (auto ev : e->look_ev)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -2374,6 +2379,51 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             remaining = 0;
         }
         const uint64_t iters0 = e->h_st->iters;
+        // Look-ahead polling (no reactive maintenance, no profiling): batch k+1 is enqueued BEFORE
+        // the host waits for the status of batch k, so the stream never drains while the host
+        // looks at a read-back.  A batch enqueued after termination is a few no-op launches
+        // (every kernel returns at once when status != RUNNING).  Each launched iteration is
+        // exactly one device iteration while the status is RUNNING, so the host's count is exact.
+        const bool lookahead = e->ill_tol <= 0.0 && !e->opts.profile && remaining > 0;
+        if (lookahead) {
+            if (!e->h_look) {
+                HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_look), 2 * sizeof(DevState), hipHostMallocDefault));
+                HIPCHK(hipEventCreateWithFlags(&e->look_ev[0], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&e->look_ev[1], hipEventDisableTiming));
+            }
+            const uint64_t lpoll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 64;
+            bool pending[2] = {false, false};
+            bool terminal = false;
+            int slot = 0;
+            while (!terminal) {
+                if (remaining > 0) {
+                    const uint64_t batch = remaining < lpoll ? remaining : lpoll;
+                    for (uint64_t it = 0; it < batch; ++it) {
+                        if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
+                        if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
+                        else launch_dual_iteration(e);
+                    }
+                    remaining -= batch;
+                    HIPCHK(hipMemcpyAsync(&e->h_look[slot], e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+                    HIPCHK(hipEventRecord(e->look_ev[slot], e->stream));
+                    pending[slot] = true;
+                }
+                const int other = slot ^ 1;
+                const int wait_on = pending[other] ? other : (remaining == 0 && pending[slot] ? slot : -1);
+                if (wait_on >= 0) {
+                    HIPCHK(hipEventSynchronize(e->look_ev[wait_on]));
+                    pending[wait_on] = false;
+                    if (e->h_look[wait_on].status != ST_RUNNING) terminal = true;
+                }
+                if (remaining == 0 && !pending[0] && !pending[1]) break;
+                slot ^= 1;
+            }
+            HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipGetLastError());
+            if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
+            remaining = 0;
+        }
         while (remaining > 0) {
             const bool chained = e->maint_chain > 0;
             const uint64_t batch = chained ? 1 : (remaining < poll ? remaining : poll);
