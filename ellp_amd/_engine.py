@@ -104,8 +104,25 @@ def lib():
     L.ellp_engine_step.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     L.ellp_engine_poll.restype = C.c_int
     L.ellp_engine_poll.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    L.ellp_comm_unique_id.restype = C.c_int
+    L.ellp_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_comm_init.restype = C.c_int
+    L.ellp_engine_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.ellp_engine_run_sharded.restype = C.c_int
+    L.ellp_engine_run_sharded.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats), C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def comm_unique_id(rccl_path=None):
+    """128-byte RCCL unique id (rank 0 creates it, the other ranks receive it)."""
+    buf = C.create_string_buffer(128)
+    err = C.create_string_buffer(512)
+    path = rccl_path.encode() if rccl_path else None
+    s = lib().ellp_comm_unique_id(path, buf, err, 512)
+    if s != OPTIMAL:
+        raise EllpHipError(s, err.value.decode())
+    return buf.raw
 
 
 def default_opts(**kw):
@@ -252,6 +269,22 @@ class Engine:
         err = C.create_string_buffer(512)
         s = lib().ellp_engine_poll(self._h, C.byref(st), err, 512)
         if s == ERR_DEVICE:
+            raise EllpHipError(s, err.value.decode())
+        return s, st, err.value.decode()
+
+    # ---- sharded loop inside the library, exchange by RCCL on the engine's stream
+    def comm_init(self, unique_id, rank, world, rccl_path=None):
+        err = C.create_string_buffer(512)
+        path = rccl_path.encode() if rccl_path else None
+        s = lib().ellp_engine_comm_init(self._h, path, bytes(unique_id), int(rank), int(world), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def run_sharded(self, max_iters):
+        st = Stats()
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_run_sharded(self._h, C.c_uint64(int(max_iters)), C.byref(st), err, 512)
+        if s == ERR_DEVICE or s == ERR_ARG:
             raise EllpHipError(s, err.value.decode())
         return s, st, err.value.decode()
 

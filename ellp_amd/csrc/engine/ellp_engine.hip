@@ -38,6 +38,8 @@
 // There is no CPU path in this file: without a HIP device every entry point returns
 // ELLP_ERR_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is bound with dlopen (see RcclApi)
 
 #include <chrono>
 #include <cmath>
@@ -1638,6 +1640,16 @@ __global__ __launch_bounds__(256) void k_gather_vec(const double *v, const int64
 
 // ====================================================================== host side
 
+// RCCL entry points, bound at run time so that the library has no link-time dependency on RCCL
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
 struct ellp_engine {
     int kind = 0;
     int64_t m = 0, n = 0, n_c = 0, nN = 0, ld = 0;
@@ -1690,6 +1702,9 @@ struct ellp_engine {
     double kernel_ms[ELLP_K_COUNT] = {0};
     uint64_t kernel_calls[ELLP_K_COUNT] = {0};
     std::vector<void *> allocs;
+    // direct RCCL exchange (ellp_engine_comm_init)
+    ncclComm_t comm = nullptr;
+    const struct RcclApi *rccl = nullptr;
 };
 
 namespace {
@@ -2060,6 +2075,7 @@ void ellp_engine_destroy(ellp_engine *e) {
     }
 #endif
     e->stream = e->own_stream;
+    if (e->comm && e->rccl) (void)e->rccl->CommDestroy(e->comm);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_st) (void)hipHostFree(e->h_st);
     if (e->h_look) (void)hipHostFree(e->h_look);
@@ -2675,6 +2691,115 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
     }
     if (e->h_st->status == ST_RUNNING) return ELLP_MAXITER;  // still running: the slice is simply used up
     return status_message(*e->h_st, errbuf, errlen);
+}
+
+// ---- direct RCCL exchange -------------------------------------------------------------------
+static const RcclApi *load_rccl(const char *path, char *errbuf, size_t errlen) {
+    static RcclApi api;  // bound once per process (dlopen of an already loaded library is a lookup)
+    static bool tried = false, ok = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {path, "librccl.so.1", "librccl.so"};
+        for (const char *nm : names) {
+            if (!nm || !nm[0]) continue;
+            api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (api.handle) {
+            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
+            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+            ok = api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString;
+        }
+    }
+    if (!ok) {
+        set_err(errbuf, errlen, "RCCL is not available (dlopen/dlsym of librccl failed: %s)", dlerror() ? dlerror() : "missing symbol");
+        return nullptr;
+    }
+    return &api;
+}
+
+ellp_status ellp_comm_unique_id(const char *rccl_path, void *id_out, char *errbuf, size_t errlen) {
+    if (!id_out) return ELLP_ERR_ARG;
+    const RcclApi *api = load_rccl(rccl_path, errbuf, errlen);
+    if (!api) return ELLP_ERR_DEVICE;
+    ncclUniqueId id;
+    const ncclResult_t rc = api->GetUniqueId(&id);
+    if (rc != ncclSuccess) {
+        set_err(errbuf, errlen, "ncclGetUniqueId: %s", api->GetErrorString(rc));
+        return ELLP_ERR_DEVICE;
+    }
+    static_assert(sizeof(ncclUniqueId) == ELLP_COMM_ID_BYTES, "unique id size");
+    memcpy(id_out, &id, sizeof(id));
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const void *id, int rank, int world,
+                                  char *errbuf, size_t errlen) {
+    if (!e || !id || world < 1 || rank < 0 || rank >= world) return ELLP_ERR_ARG;
+    const RcclApi *api = load_rccl(rccl_path, errbuf, errlen);
+    if (!api) return ELLP_ERR_DEVICE;
+    HIPCHK(hipSetDevice(e->device));
+    const ellp_status s = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // engine-owned buffer
+    if (s != ELLP_OPTIMAL) return s;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    if (e->comm) {
+        (void)api->CommDestroy(e->comm);
+        e->comm = nullptr;
+    }
+    const ncclResult_t rc = api->CommInitRank(&e->comm, world, uid, rank);
+    if (rc != ncclSuccess) {
+        set_err(errbuf, errlen, "ncclCommInitRank: %s", api->GetErrorString(rc));
+        e->comm = nullptr;
+        return ELLP_ERR_DEVICE;
+    }
+    e->rccl = api;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_run_sharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf,
+                                    size_t errlen) {
+    if (!e) return ELLP_ERR_ARG;
+    if (!e->comm || !e->rccl) {
+        set_err(errbuf, errlen, "ellp_engine_comm_init has not been called");
+        return ELLP_ERR_ARG;
+    }
+    if (errbuf && errlen) errbuf[0] = 0;
+    HIPCHK(hipSetDevice(e->device));
+    auto t0 = std::chrono::steady_clock::now();
+    ellp_stats local;
+    ellp_stats *sp = stats ? stats : &local;
+    ellp_status result = ellp_engine_poll(e, sp, errbuf, errlen);  // a previous slice may have terminated
+    const uint64_t iters0 = sp->iters;
+    uint64_t remaining = max_iters;
+    const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 32;
+    const double *mine = e->X + (int64_t)e->rank * e->seg;
+    while (result == ELLP_MAXITER && remaining > 0 && e->nN > 0) {
+        const uint64_t batch = remaining < poll ? remaining : poll;
+        // one collective per iteration: step(2) = rest of iteration k + pricing of iteration k+1
+        ellp_status s = ellp_engine_step(e, 0, errbuf, errlen);
+        for (uint64_t k = 0; k < batch && s == ELLP_OPTIMAL; ++k) {
+            const ncclResult_t rc =
+                e->rccl->AllGather(mine, e->X, (size_t)e->seg, ncclDouble, e->comm, e->stream);  // in place
+            if (rc != ncclSuccess) {
+                set_err(errbuf, errlen, "ncclAllGather: %s", e->rccl->GetErrorString(rc));
+                return ELLP_ERR_DEVICE;
+            }
+            s = ellp_engine_step(e, k + 1 < batch ? 2 : 1, errbuf, errlen);
+        }
+        if (s != ELLP_OPTIMAL) return s;
+        result = ellp_engine_poll(e, sp, errbuf, errlen);
+        // iterations that really ran (a maintenance request voids the rest of its batch); the
+        // device state is replicated, so every rank computes the same `remaining`
+        const uint64_t done = sp->iters - iters0;
+        remaining = done < max_iters ? max_iters - done : 0;
+    }
+    if (e->nN == 0) result = ELLP_OPTIMAL;
+    if (stats) stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return result;
 }
 
 static ellp_status solve_once(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,

@@ -48,10 +48,25 @@ def all_gather_segments(full, mine, rank, world, group=None):
     full.copy_(torch.cat(parts).to(full.device))
 
 
-class ShardedEngine:
-    """Drives one `Engine` per rank with the pricing pass sharded over the process group."""
+def _torch_rccl_path():
+    """The RCCL library this process already uses through torch (so the engine binds the same copy)."""
+    import os
+    import torch
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else None
 
-    def __init__(self, kind, fp, opts=None, group=None):
+
+class ShardedEngine:
+    """Drives one `Engine` per rank with the pricing pass sharded over the process group.
+
+    exchange="rccl" (default with backend nccl): the per-iteration loop runs inside the library
+    (`ellp_engine_run_sharded`) and the all-gather is an in-place ncclAllGather on the engine's own
+    stream; torch.distributed only carries the 128-byte unique id once.  exchange="torch": the loop
+    runs here, one `all_gather_into_tensor` per iteration (the only choice with backend gloo; also
+    the fallback if RCCL cannot be bound).  ELLP_DIST_EXCHANGE overrides."""
+
+    def __init__(self, kind, fp, opts=None, group=None, exchange=None):
+        import os
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -60,6 +75,15 @@ class ShardedEngine:
         else:
             self.rank, self.world = 0, 1
         self.eng = E.Engine(kind, fp, opts)
+        backend = dist.get_backend(group) if self.world > 1 else None
+        exchange = exchange or os.environ.get("ELLP_DIST_EXCHANGE") or ("rccl" if backend == "nccl" else "torch")
+        self.direct = False
+        if exchange == "rccl":
+            self.direct = self._init_direct(backend)
+        if self.direct:
+            self.seg = self.eng.segment_doubles(self.world)
+            self.stream = None
+            return
         # the exchange buffer is a torch allocation handed to the engine, so the collective
         # library works on memory it knows
         self.seg = seg = self.eng.segment_doubles(self.world)
@@ -74,7 +98,39 @@ class ShardedEngine:
         assert self.stream.cuda_stream != 0
         self.eng.set_stream(self.stream.cuda_stream)
         self.mine = self.full[self.rank * seg:(self.rank + 1) * seg]  # this rank's slice (a view)
-        self.nccl = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.nccl = self.world > 1 and backend == "nccl"
+
+    def _init_direct(self, backend):
+        """Unique id from rank 0 to everyone over the process group, then ncclCommInitRank in the
+        library.  Every rank reports whether it succeeded; the direct path is used only if all did
+        (otherwise all fall back together — the ranks must agree on the sequence of collectives)."""
+        torch, dist = self.torch, self.dist
+        path = _torch_rccl_path()
+        dev = "cuda" if backend == "nccl" else "cpu"
+        ok = 1
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if self.rank == 0:
+            try:
+                raw = E.comm_unique_id(path)
+                uid.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            except Exception:
+                ok = 0
+        if self.world > 1:
+            dist.broadcast(uid, src=0, group=self.group)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            return False
+        try:
+            self.eng.comm_init(bytes(uid.cpu().numpy().tobytes()), self.rank, self.world, path)
+            ok = 1
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
 
     def exchange(self):
         """Must be called with self.stream current (run() does)."""
@@ -88,6 +144,8 @@ class ShardedEngine:
 
     def run(self, max_iters, poll_interval=16):
         """Up to `max_iters` further iterations; returns (status, Stats, message) like Engine.run."""
+        if self.direct:
+            return self.eng.run_sharded(max_iters)
         done = 0
         with self.torch.cuda.stream(self.stream):
             status, stats, msg = self.eng.poll()
@@ -108,6 +166,7 @@ class ShardedEngine:
         return self.eng.read_point()
 
     def close(self):
-        self.stream.synchronize()
-        self.eng.set_stream(None)
+        if self.stream is not None:
+            self.stream.synchronize()
+            self.eng.set_stream(None)
         self.eng.close()

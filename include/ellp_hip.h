@@ -189,6 +189,24 @@ ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream);
 ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t errbuf_len);
 ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, size_t errbuf_len);
 
+/*
+ * The same sharded loop driven from inside the library, with the exchange done by RCCL directly
+ * on the engine's stream (ncclAllGather, in place, seg doubles per rank) — no host language in the
+ * per-iteration path.  RCCL is bound at run time (dlopen; `rccl_path` may name the library the
+ * process already uses, e.g. torch's copy; NULL = "librccl.so.1"), so a single-GPU user of this
+ * library needs no RCCL.  Rank 0 calls ellp_comm_unique_id(), the 128 bytes travel to the other
+ * ranks by any means (torch.distributed broadcast in ellp_amd/dist.py), every rank calls
+ * ellp_engine_comm_init() (collective), then ellp_engine_run_sharded() (collective: every rank
+ * must pass the same max_iters; the ranks take identical decisions, so they issue identical
+ * sequences of collectives).  Returns like ellp_engine_run.
+ */
+#define ELLP_COMM_ID_BYTES 128
+ellp_status ellp_comm_unique_id(const char *rccl_path, void *id_out, char *errbuf, size_t errbuf_len);
+ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const void *id, int rank, int world,
+                                  char *errbuf, size_t errbuf_len);
+ellp_status ellp_engine_run_sharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf,
+                                    size_t errbuf_len);
+
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
 enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,

@@ -115,3 +115,41 @@ def test_stepped_api_world1_matches_run():
     assert st1 == st2 == E.OPTIMAL and s1.iters == s2.iters
     np.testing.assert_array_equal(a.B, b.B)
     np.testing.assert_array_equal(a.x, b.x)
+
+
+def test_library_loop_with_direct_rccl_world1():
+    """ellp_engine_run_sharded: the per-iteration loop inside the library with an in-place
+    ncclAllGather on the engine's stream.  A one-GPU box can only form a 1-rank communicator
+    (RCCL refuses two ranks on one device), which still exercises the run-time binding of RCCL,
+    ncclCommInitRank, the collective on the engine's stream and the loop; the multi-rank exchange
+    layout is covered by the world-2 test above through the same step API."""
+    from ellp_amd import _engine as E
+    from ellp_amd.dist import ShardedEngine
+    for kind, make in ((E.ENGINE_PRIMAL, lambda: _flat(20260301, 200, 500)), (E.ENGINE_DUAL, _dual_flat)):
+        opts = E.default_opts(max_iter=None, device=0)
+        ref_fp = make()
+        ref = E.Engine(kind, ref_fp, opts)
+        st_ref, stats_ref, _ = ref.run(3000)
+        ref.read_point()
+        ref.close()
+        fp = make()
+        sh = ShardedEngine(kind, fp, opts, exchange="rccl")
+        assert sh.direct, "RCCL could not be bound"
+        st, stats, msg = sh.run(1000)       # two slices: the loop resumes where it stopped
+        if st == E.MAXITER:
+            st, stats, msg = sh.run(2000)
+        sh.read_point()
+        sh.close()
+        assert st == st_ref, msg
+        assert stats.iters == stats_ref.iters
+        np.testing.assert_array_equal(fp.B, ref_fp.B)
+        np.testing.assert_array_equal(fp.N, ref_fp.N)
+        np.testing.assert_array_equal(fp.x, ref_fp.x)
+
+
+def test_run_sharded_needs_a_communicator():
+    from ellp_amd import _engine as E
+    eng = E.Engine(E.ENGINE_PRIMAL, _flat(3, 20, 50), E.default_opts(max_iter=None, device=0))
+    with pytest.raises(E.EllpHipError):
+        eng.run_sharded(10)
+    eng.close()
