@@ -109,12 +109,12 @@ class ShardedEngine:
         dev = "cuda" if backend == "nccl" else "cpu"
         ok = 1
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if self.rank == 0:
-            try:
-                raw = E.comm_unique_id(path)
+        try:  # every rank binds RCCL here (and votes below) BEFORE anyone enters the blocking init
+            raw = E.comm_unique_id(path)
+            if self.rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
-            except Exception:
-                ok = 0
+        except Exception:
+            ok = 0
         if self.world > 1:
             dist.broadcast(uid, src=0, group=self.group)
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
