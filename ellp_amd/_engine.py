@@ -104,6 +104,8 @@ def lib():
     L.ellp_engine_step.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     L.ellp_engine_poll.restype = C.c_int
     L.ellp_engine_poll.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    L.ellp_engine_rephase.restype = C.c_int
+    L.ellp_engine_rephase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
     L.ellp_comm_unique_id.restype = C.c_int
     L.ellp_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
     L.ellp_engine_comm_init.restype = C.c_int
@@ -271,6 +273,19 @@ class Engine:
         if s == ERR_DEVICE:
             raise EllpHipError(s, err.value.decode())
         return s, st, err.value.decode()
+
+    def rephase(self, c, kind, lb, ub):
+        """Primal phase-1 -> phase-2 hand-off on the device (costs and bounds replaced; basis, point
+        and B^-1 stay).  The FlatProblem's c/kind/lb/ub are updated too."""
+        fp = self.fp
+        fp.c = _f64(c)
+        fp.kind = np.ascontiguousarray(kind, dtype=np.uint8)
+        fp.lb, fp.ub = _f64(lb), _f64(ub)
+        assert fp.c.size == fp.n_c == fp.kind.size == fp.lb.size == fp.ub.size
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_rephase(self._h, _p(fp.c), _p(fp.kind), _p(fp.lb), _p(fp.ub), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
 
     # ---- sharded loop inside the library, exchange by RCCL on the engine's stream
     def comm_init(self, unique_id, rank, world, rccl_path=None):

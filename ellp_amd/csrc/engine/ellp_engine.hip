@@ -1636,6 +1636,20 @@ __global__ __launch_bounds__(256) void k_gather_vec(const double *v, const int64
     if (k < n) dst[k] = v[index[k]];
 }
 
+// phase hand-off (ellp_engine_rephase): re-gather the costs by the current index sets and relabel the
+// nonbasic variables that became Free
+__global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t *kind, const int64_t *B_index,
+                                                 const int64_t *N_index, double *c_B, double *c_N, uint8_t *Nb,
+                                                 int64_t m, int64_t nN) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < m) c_B[k] = c[B_index[k]];
+    if (k < nN) {
+        const int64_t j = N_index[k];
+        c_N[k] = c[j];
+        if (kind[j] == ELLP_BOUND_FREE) Nb[k] = ELLP_NB_FREE;
+    }
+}
+
 }  // namespace
 
 // ====================================================================== host side
@@ -2691,6 +2705,55 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
     }
     if (e->h_st->status == ST_RUNNING) return ELLP_MAXITER;  // still running: the slice is simply used up
     return status_message(*e->h_st, errbuf, errlen);
+}
+
+ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *bound_kind, const double *lb,
+                                const double *ub, char *errbuf, size_t errlen) {
+    if (!e || !c || !bound_kind || !lb || !ub) return ELLP_ERR_ARG;
+    if (errbuf && errlen) errbuf[0] = 0;
+    if (e->kind != ELLP_ENGINE_PRIMAL) {
+        set_err(errbuf, errlen, "rephase is the primal phase-1 -> phase-2 hand-off");
+        return ELLP_ERR_ARG;
+    }
+    for (int64_t i = 0; i < e->n_c; ++i)
+        if (bound_kind[i] > 4) {
+            set_err(errbuf, errlen, "bound_kind[%lld] out of range", (long long)i);
+            return ELLP_ERR_ARG;
+        }
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double *c_dev = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c_dev), sizeof(double) * (size_t)e->n_c));
+    auto bail = [&](hipError_t err) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(c_dev);
+        set_err(errbuf, errlen, "HIP error %s in ellp_engine_rephase", hipGetErrorString(err));
+        return ELLP_ERR_DEVICE;
+    };
+    hipError_t rc;
+    if ((rc = hipMemcpyAsync(c_dev, c, sizeof(double) * (size_t)e->n_c, hipMemcpyHostToDevice, e->stream)) != hipSuccess) return bail(rc);
+    if ((rc = hipMemcpyAsync(e->lb, lb, sizeof(double) * (size_t)e->n_c, hipMemcpyHostToDevice, e->stream)) != hipSuccess) return bail(rc);
+    if ((rc = hipMemcpyAsync(e->ub, ub, sizeof(double) * (size_t)e->n_c, hipMemcpyHostToDevice, e->stream)) != hipSuccess) return bail(rc);
+    if ((rc = hipMemcpyAsync(e->kindv, bound_kind, (size_t)e->n_c, hipMemcpyHostToDevice, e->stream)) != hipSuccess) return bail(rc);
+    const int64_t cnt = e->m > e->nN ? e->m : e->nN;
+    hipLaunchKernelGGL(k_rephase, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, c_dev, e->kindv,
+                       e->B_index, e->N_index, e->c_B, e->c_N, e->Nb, e->m, e->nN);
+    // a new solve_with_initial starts here: status, counters and flags afresh; B^-1 and `cur` stay
+    if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return bail(rc);
+    if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return bail(rc);
+    DevState ns = *e->h_st;
+    ns.status = ST_RUNNING;
+    ns.nan_flag = 0;
+    ns.panic_code = 0;
+    ns.iters = ns.pivots = ns.flips = 0;
+    ns.lambda = 0.0;
+    *e->h_st = ns;
+    if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return bail(rc);
+    if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return bail(rc);
+    (void)hipFree(c_dev);
+    e->u_valid = false;  // u = B^-T c_B with the new costs
+    e->maint_chain = 0;
+    return ELLP_OPTIMAL;
 }
 
 // ---- direct RCCL exchange -------------------------------------------------------------------

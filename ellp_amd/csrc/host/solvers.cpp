@@ -95,13 +95,60 @@ SolutionStatus PrimalSimplexSolver::solve_with_initial(const StandardForm &sf, P
     return out;
 }
 
-// primal_simplex_solver.rs:32-93
+namespace {
+
+// owns a resident engine for the two phases of one primal solve
+struct EngineHandle {
+    ellp_engine *e = nullptr;
+    ~EngineHandle() { if (e) ellp_engine_destroy(e); }
+};
+
+// one phase on a resident engine: run, then bring the point back (x, B, N as at the seam)
+SolutionStatus run_resident(ellp_engine *e, std::uint64_t max_iter, Flat &f, Point &pt, std::uint64_t *iters) {
+    ellp_stats st{};
+    char err[512] = {0};
+    const ellp_status s = ellp_engine_run(e, max_iter, &st, err, sizeof(err));
+    if (iters) *iters = st.iters;
+    const SolutionStatus out = to_status(s, err);
+    const ellp_status rs = ellp_engine_read_point(e, pt.x.data(), f.B.data(), f.N.data(), f.Nb.data(), nullptr,
+                                                  nullptr, err, sizeof(err));
+    if (rs != ELLP_OPTIMAL) to_status(rs, err);
+    unflatten(f, pt);
+    return out;
+}
+
+}  // namespace
+
+// primal_simplex_solver.rs:32-93.  The two solve_with_initial calls of the reference become two
+// slices of ONE resident engine: after phase 1 only the costs and bounds are replaced on the
+// device (ellp_engine_rephase, primal_problem.rs:263-291) — the matrix, the basis and B^-1 stay in
+// HBM.  Problems the seam never sends to the device (m == 0, no nonbasic column) take the plain path.
 SolverResult PrimalSimplexSolver::solve(Problem prob) const {
     SolverResult res;
     auto p1 = PrimalPhase1::from_problem(std::move(prob));
     if (!p1) { res.kind = SolverResult::Infeasible; return res; }
     PrimalPhase1 phase_1 = std::move(*p1);
-    switch (solve_with_initial(phase_1.std_form, phase_1.point, &res.iters_phase1)) {
+    const bool resident = phase_1.std_form.rows() > 0 && !phase_1.point.N.empty();
+    EngineHandle eng;
+    Flat f1;
+    SolutionStatus s1;
+    if (resident) {
+        f1 = flatten(phase_1.std_form, phase_1.point);
+        const StandardForm &sf = phase_1.std_form;
+        const ellp_opts o = make_opts(max_iter_, engine_);
+        char err[512] = {0};
+        const ellp_status cs = ellp_engine_create(
+            ELLP_ENGINE_PRIMAL, static_cast<std::int64_t>(sf.rows()), static_cast<std::int64_t>(sf.cols()),
+            static_cast<std::int64_t>(sf.bounds.size()), sf.A.a.data(), sf.c.data(), sf.b.data(), f1.kind.data(),
+            f1.lb.data(), f1.ub.data(), phase_1.point.x.data(), f1.B.data(), static_cast<std::int64_t>(f1.B.size()),
+            f1.N.data(), f1.Nb.data(), static_cast<std::int64_t>(f1.N.size()), nullptr, nullptr, &o, &eng.e, err,
+            sizeof(err));
+        if (cs != ELLP_OPTIMAL) to_status(cs, err);  // throws: Err(EllPError) / panic / device
+        s1 = run_resident(eng.e, max_iter_, f1, phase_1.point, &res.iters_phase1);
+    } else {
+        s1 = solve_with_initial(phase_1.std_form, phase_1.point, &res.iters_phase1);
+    }
+    switch (s1) {
     case SolutionStatus::Optimal: {
         const double obj = phase_1.obj();
         if (!(obj > -EPS)) throw EllPPanic("assertion failed: obj > -EPS");
@@ -116,7 +163,18 @@ SolverResult PrimalSimplexSolver::solve(Problem prob) const {
         return res;
     }
     PrimalPhase2 phase_2 = PrimalPhase2::from_phase1(std::move(phase_1));
-    switch (solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2)) {
+    SolutionStatus s2;
+    if (resident) {
+        Flat f2 = flatten(phase_2.std_form, phase_2.point);
+        char err[512] = {0};
+        const ellp_status rs = ellp_engine_rephase(eng.e, phase_2.std_form.c.data(), f2.kind.data(), f2.lb.data(),
+                                                   f2.ub.data(), err, sizeof(err));
+        if (rs != ELLP_OPTIMAL) to_status(rs, err);
+        s2 = run_resident(eng.e, max_iter_, f2, phase_2.point, &res.iters_phase2);
+    } else {
+        s2 = solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2);
+    }
+    switch (s2) {
     case SolutionStatus::Optimal:
         res.kind = SolverResult::Optimal;
         res.solution = Solution{std::move(phase_2.std_form), std::move(phase_2.point)};

@@ -190,6 +190,16 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
 ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, size_t errbuf_len);
 
 /*
+ * Phase-1 -> phase-2 hand-off of the primal method without leaving HBM (SURVEY.md §8 f2;
+ * primal_problem.rs:263-291): the matrix, the basis, the point and B^-1 stay where they are; the
+ * costs and bounds (n_c entries each) are replaced, and a nonbasic variable whose new bound is Free
+ * gets the label Free (:285-289).  Status and counters start afresh, as for a new
+ * solve_with_initial call.  Primal engines only.
+ */
+ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *bound_kind, const double *lb,
+                                const double *ub, char *errbuf, size_t errbuf_len);
+
+/*
  * The same sharded loop driven from inside the library, with the exchange done by RCCL directly
  * on the engine's stream (ncclAllGather, in place, seg doubles per rank) — no host language in the
  * per-iteration path.  RCCL is bound at run time (dlopen; `rccl_path` may name the library the
