@@ -67,7 +67,8 @@ typedef struct ellp_opts {
     int32_t btran_mode;      /* 0 default (incremental u, periodic refresh); 1 = u = B^-T c_B every iteration */
     int32_t poll_interval;   /* iterations enqueued between host polls of the status word; <= 0 = default */
     int32_t profile;         /* != 0: bracket every launch with HIP events (ellp_stats.kernel_ms) */
-    int32_t use_graph;       /* != 0: replay the per-iteration launch sequence from a hipGraph */
+    int32_t use_graph;       /* reserved, must be 0 (hipGraph replay of the launch sequence is not implemented:
+                                on gfx950 the per-iteration cost is GPU-side dispatch, not host launches) */
     int32_t reserved[4];
 } ellp_opts;
 
