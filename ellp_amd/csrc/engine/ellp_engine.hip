@@ -2758,27 +2758,27 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
 
 // ---- direct RCCL exchange -------------------------------------------------------------------
 static const RcclApi *load_rccl(const char *path, char *errbuf, size_t errlen) {
-    static RcclApi api;  // bound once per process (dlopen of an already loaded library is a lookup)
-    static bool tried = false, ok = false;
-    if (!tried) {
-        tried = true;
+    // bound once per process; the initialisation of a function-local static is thread-safe, and
+    // dlopen of a library the process already has is a lookup
+    static const RcclApi api = [path] {
+        RcclApi a;
         const char *names[] = {path, "librccl.so.1", "librccl.so"};
         for (const char *nm : names) {
             if (!nm || !nm[0]) continue;
-            api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-            if (api.handle) break;
+            a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (a.handle) break;
         }
-        if (api.handle) {
-            api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
-            api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
-            api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(api.handle, "ncclAllGather"));
-            api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
-            api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
-            ok = api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString;
+        if (a.handle) {
+            a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
+            a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
+            a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
+            a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+            a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
         }
-    }
-    if (!ok) {
-        set_err(errbuf, errlen, "RCCL is not available (dlopen/dlsym of librccl failed: %s)", dlerror() ? dlerror() : "missing symbol");
+        return a;
+    }();
+    if (!(api.handle && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy && api.GetErrorString)) {
+        set_err(errbuf, errlen, "RCCL is not available (dlopen/dlsym of librccl failed)");
         return nullptr;
     }
     return &api;
