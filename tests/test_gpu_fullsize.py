@@ -137,3 +137,49 @@ def test_c4_dual_invariants_over_a_long_run(dual_flat):
         assert abs(dual_obj - stats.obj) < 1e-6 * (1 + abs(dual_obj))  # incremental obj (dual…:316) tracks it
         prev = dual_obj
     eng.close()
+
+
+# ---- m >= 3072: k_update2 takes 8 rows per block (second group streamed) and k_ftran2 streams its
+# rows (no register prefetch) — the geometry of config 5 (m = 4000), at a size the checkers can afford
+M_BIG, N_BIG = 3104, 3500
+
+
+def test_big_m_primal_window_parity():
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(SEED, M_BIG, N_BIG)
+    W = 400
+    ov = _view(f)
+    st_o, it_o, msg_o, _ = eo.primal_binv_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    st_g, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, (msg, msg_o)
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_array_equal(fp.Nb, ov.Nb)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
+
+
+def test_big_m_dual_window_parity():
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+    f = synth.dual_start_flat(SEED, M_BIG, N_BIG)
+    W = 6
+    ov = _view(f)
+    st_o, it_o, _ = eo.dual_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"], f["y"], f["d"])
+    eng = E.Engine(E.ENGINE_DUAL, fp, E.default_opts(max_iter=None))
+    st_g, stats, msg = eng.run(W)
+    eng.read_point()
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, msg
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-9 * (1 + np.abs(ov.x).max()))
+    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-9 * (1 + np.abs(ov.d).max()))
+    # and 300 more pivots keep B^-1 an inverse (every row block, both row groups, was rewritten)
+    st_g, stats, msg = eng.run(300)
+    assert st_g == E.MAXITER, msg
+    assert eng.inverse_residual() < 1e-10
+    eng.close()
