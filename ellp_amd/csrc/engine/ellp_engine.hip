@@ -55,7 +55,12 @@
 namespace {
 
 constexpr int ST_RUNNING = 100;
-constexpr int ST_NEED_MAINT = 101;  // internal: a tiny pivot was taken; refresh B^-1 before going on
+// internal: a tiny pivot was taken; refresh B^-1 before going on.  k_update2 only raises
+// DevState::tiny — if it wrote the status itself, blocks of the SAME launch that start late (the GPU
+// is shared with other solves) would see it at their entry check and skip their rows of the eta
+// update.  The leader of the next pricing launch turns the flag into this status, so every later
+// kernel of the batch sees it from its first instruction and the rest of the batch is void.
+constexpr int ST_NEED_MAINT = 101;
 constexpr int WAVE = 64;
 
 struct DevState {
@@ -73,7 +78,8 @@ struct DevState {
     double ldelta;
     int32_t lside, l_pad;
     // ---- refactorisation (single-block k_ref_pick -> k_ref_update)
-    int32_t do_update, r_pad;
+    int32_t do_update;
+    int32_t tiny;  // k_update2's bookkeeping block: the pivot just taken was tiny (see ST_NEED_MAINT)
     int64_t r, refk;
     double d_r, alpha_r;
     // ---- results
@@ -187,6 +193,14 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     __shared__ long long s_p[4];
     DevState *st = a.st;
     if (st->status != ST_RUNNING) return;
+    if (st->tiny) {  // raised by the previous k_update2: stop the batch here (see ST_NEED_MAINT)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->status = ST_NEED_MAINT;
+            __threadfence();
+            st->tiny = 0;
+        }
+        return;
+    }
     STAMP(0, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t half = a.ld >> 1;
@@ -215,6 +229,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     const int gb = a.block0 + (int)blockIdx.x;  // global pricing block
     const int64_t j0 = (int64_t)gb * a.cpb;
     const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
+    if (j0 >= a.nN) return;  // a rank without pricing blocks still launches one block for the flag above
     double best = (MODE == 0) ? -INFINITY : INFINITY;
     long long bestpos = -1;
     int buf = 0;
@@ -307,6 +322,158 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
         if (tid < 4) {
             s_k[tid] = best;
             s_p[tid] = bestpos;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double bk = INFINITY;
+            long long bp = -1;
+            for (int k = 0; k < 4; ++k) {
+                if (s_p[k] < 0) continue;
+                if (bp < 0 || s_k[k] < bk || (s_k[k] == bk && s_p[k] < bp)) {
+                    bk = s_k[k];
+                    bp = s_p[k];
+                }
+            }
+            a.xc.bk(gb) = bk;
+            a.xc.bp(gb) = (double)bp;
+        }
+    }
+    STAMP(0, 1);
+}
+
+// Wave-per-column variant for the cache-resident regime (8*ld*|N| within reach of the 256 MiB
+// Infinity Cache): the block's four waves each own column pairs j0+2w, j0+2w+1 (+8, ...), every
+// lane keeps 2 x 4 16-byte column loads in flight and re-reads its slice of u from L1/L2, and there
+// is no block barrier inside the stream — only one at the end to combine the four waves' results.
+// tools/price_bench.hip: 17.3 us against 18.3 us for the block-per-column-group shape at C3 (and no
+// gain once A_N streams from HBM, where k_price<.,.,true> is used).  Same outputs as k_price.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
+    __shared__ double s_k[4];
+    __shared__ long long s_p[4];
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    if (st->tiny) {  // raised by the previous k_update2: stop the batch here (see ST_NEED_MAINT)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->status = ST_NEED_MAINT;
+            __threadfence();
+            st->tiny = 0;
+        }
+        return;
+    }
+    STAMP(0, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t half = a.ld >> 1;
+    double sgn = 1.0;
+    const double2 *u2;
+    if (MODE == 0) {
+        u2 = reinterpret_cast<const double2 *>(a.u);
+    } else {
+        const int64_t lr = st->lr;
+        if (lr < 0) {  // no primal-infeasible basic: optimal (dual…:243-246)
+            if (blockIdx.x == 0 && tid == 0) {
+                st->iters += 1;
+                st->status = ELLP_OPTIMAL;
+            }
+            return;
+        }
+        sgn = (st->ldelta < 0.0) ? -1.0 : 1.0;
+        u2 = reinterpret_cast<const double2 *>((st->cur ? a.W1 : a.W0) + lr * a.ld);
+    }
+    const int gb = a.block0 + (int)blockIdx.x;  // global pricing block
+    const int64_t j0 = (int64_t)gb * a.cpb;
+    const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
+    if (j0 >= a.nN) return;  // a rank without pricing blocks still launches one block for the flag above
+    double best = (MODE == 0) ? -INFINITY : INFINITY;  // lanes 0 and 1 own the pair's two columns
+    long long bestpos = -1;
+    for (int64_t j = j0 + 2 * wave; j < j1; j += 8) {
+        const int ncol = (j1 - j) < 2 ? 1 : 2;
+        int nb_pre = 0;
+        double cd_pre = 0.0;  // primal: c_N[j] ; dual: d[N_index[j]]
+        {
+            const int64_t jo = j + (lane < ncol ? lane : 0);
+            nb_pre = a.Nb[jo];
+            cd_pre = (MODE == 0) ? a.c_N[jo] : a.dd[a.N_index[jo]];
+        }
+        const double2 *c0 = reinterpret_cast<const double2 *>(a.A_N + j * a.ld);
+        const double2 *c1 = reinterpret_cast<const double2 *>(a.A_N + (j + 1 < j1 ? j + 1 : j) * a.ld);
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int64_t t0 = lane; t0 < half; t0 += 4 * WAVE) {
+            double2 uu[4], v0[4], v1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t t = t0 + WAVE * k;
+                const int64_t tc = t < half ? t : 0;  // clamped, unconditional
+                const double2 uv = u2[tc];
+                uu[k] = t < half ? uv : make_double2(0.0, 0.0);
+                v0[k] = c0[tc];
+                v1[k] = c1[tc];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc0 = fma(v0[k].x, uu[k].x, acc0);
+                acc0 = fma(v0[k].y, uu[k].y, acc0);
+                acc1 = fma(v1[k].x, uu[k].x, acc1);
+                acc1 = fma(v1[k].y, uu[k].y, acc1);
+            }
+        }
+        acc0 = wave_sum(acc0);
+        acc1 = wave_sum(acc1);
+        if (lane < ncol) {
+            const double dot = lane == 0 ? acc0 : acc1;
+            const int64_t jj = j + lane;
+            const int nb = nb_pre;
+            if (MODE == 0) {
+                const double rj = cd_pre - dot;
+                double key = -INFINITY;
+                if (rj != rj) {
+                    st->nan_flag = 1;
+                } else if (!(fabs(rj) < a.eps)) {
+                    const bool pos = rj > 0.0;
+                    if (pos && nb == ELLP_NB_UPPER) key = rj;
+                    else if (!pos && nb == ELLP_NB_LOWER) key = -rj;
+                    else if (nb == ELLP_NB_FREE) key = fabs(rj);
+                }
+                a.xc.r(jj) = rj;
+                a.xc.key(jj) = key;
+                best = fmax(best, key);
+            } else {
+                a.xc.r(jj) = dot;  // alpha (un-negated, dual…:286-288 restores the sign anyway)
+                const double al = sgn * dot;
+                bool keep;
+                if (nb == ELLP_NB_LOWER) keep = al > a.eps;
+                else if (nb == ELLP_NB_UPPER) keep = al < -a.eps;
+                else keep = true;
+                if (keep) {
+                    const double ratio = cd_pre / al;
+                    if (ratio != ratio) st->nan_flag = 1;
+                    if (bestpos < 0 || ratio < best) {  // this lane's columns come in increasing position
+                        best = ratio;
+                        bestpos = jj;
+                    }
+                }
+            }
+        }
+    }
+    // combine: lanes 0/1 of each wave, then the four waves (lexicographic (ratio, position) for the dual)
+    if (MODE == 0) {
+        double v = (lane < 2) ? best : -INFINITY;
+        v = fmax(v, __shfl_xor(v, 1));
+        if (lane == 0) s_k[wave] = v;
+        __syncthreads();
+        if (tid == 0) a.xc.bk(gb) = fmax(fmax(s_k[0], s_k[1]), fmax(s_k[2], s_k[3]));
+    } else {
+        double k0 = (lane < 2) ? best : INFINITY;
+        long long p0 = (lane < 2) ? bestpos : -1;
+        const double k1 = __shfl_xor(k0, 1);
+        const long long p1 = __shfl_xor(p0, 1);
+        if (p1 >= 0 && (p0 < 0 || k1 < k0 || (k1 == k0 && p1 < p0))) {
+            k0 = k1;
+            p0 = p1;
+        }
+        if (lane == 0) {
+            s_k[wave] = k0;
+            s_p[wave] = p0;
         }
         __syncthreads();
         if (tid == 0) {
@@ -1197,7 +1364,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->cur = cur ^ 1;
                 st->pivots += 1;
                 st->iters += 1;
-                if (tiny_pivot) st->status = ST_NEED_MAINT;
+                if (tiny_pivot) st->tiny = 1;
             }
         } else if (tid == 0) {  // primal…:223-231
             const int nbq = a.Nb[q];
@@ -1262,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         }
         __syncthreads();
         find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, m, tid, s_tmp, st);
-        if (tid == 0 && tiny_pivot && st->status == ST_RUNNING) st->status = ST_NEED_MAINT;
+        if (tid == 0 && tiny_pivot && st->status == ST_RUNNING) st->tiny = 1;
     }
     STAMP(2, 4);
 }
@@ -1704,6 +1871,7 @@ struct ellp_engine {
     // launch geometry
     int cpb = 1, nblocks = 1, priceT = 1;
     bool price_nt = false;
+    bool price_wave = false;  // wave-per-column pricing (cache-resident A_N, rows long enough to fill a wave)
     int upd_rows = 4, upd_blocks = 1;    // refactorisation kernels (<= UPD_ROWS rows per block)
     int upd2_rows = 4, upd2_blocks = 1;  // k_update2 (<= 2*UPD_ROWS)
     int ftran_blocks = 1;
@@ -1846,8 +2014,12 @@ void launch_price(ellp_engine *e) {
     a.eps = e->eps;
     int mine = e->nblocks - a.block0;
     if (mine > e->nbs) mine = e->nbs;
-    if (mine <= 0) return;  // this rank's shard is empty (more ranks than pricing blocks)
+    if (mine <= 0) mine = 1;  // empty shard (more ranks than pricing blocks): the block only serves DevState::tiny
     dim3 g(mine), b(256);
+    if (e->price_wave) {
+        hipLaunchKernelGGL((k_price_wave<MODE>), g, b, 0, e->stream, a);
+        return;
+    }
     if (e->price_nt) {
         switch (e->priceT) {
         case 1: hipLaunchKernelGGL((k_price<1, MODE, true>), g, b, 0, e->stream, a); break;
@@ -1975,13 +2147,17 @@ void maintain_inverse(ellp_engine *e) {
 // After a status read-back: if a kernel asked for maintenance, do it, re-arm the loop and report
 // true (the caller keeps going).  The flagged iteration committed nothing, so it is simply redone.
 bool service_maintenance_request(ellp_engine *e) {
-    if (e->h_st->status != ST_NEED_MAINT) return false;
+    // the request is the status (a later pricing launch of the batch saw the flag) or still the flag
+    // (the batch ended with the k_update2 that raised it)
+    if (e->h_st->status != ST_NEED_MAINT && !(e->h_st->status == ST_RUNNING && e->h_st->tiny)) return false;
     maintain_inverse(e);
     e->maint_chain = 1;
-    const int32_t running = ST_RUNNING;
+    const int32_t running = ST_RUNNING, zero = 0;
     (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    (void)hipMemcpyAsync(&e->st->tiny, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     (void)hipStreamSynchronize(e->stream);
     e->h_st->status = ST_RUNNING;
+    e->h_st->tiny = 0;
     e->maint_requests += 1;
     return true;
 }
@@ -2213,6 +2389,10 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         int64_t cpb = e->price_nt ? (n_N + 2047) / 2048 : (n_N + 1023) / 1024;
         if (cpb < 1) cpb = 1;
         if (cpb > 64) cpb = 64;
+        // wave-per-column pricing: cache-resident A_N, rows that fill a wave, and >= 5 columns per
+        // block so that all four waves of a block have a column pair (measured at C3/C4: 18.9 -> 18.0
+        // and 15.8 -> 14.3 us; the number of columns per block between 5 and 16 makes no difference)
+        e->price_wave = !e->price_nt && ld >= 512 && cpb >= 5;
         e->cpb = (int)cpb;
         e->nblocks = (int)((nNa + cpb - 1) / cpb);
         const int64_t need = ((ld >> 1) + 255) / 256;
@@ -2758,6 +2938,7 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     DevState ns = *e->h_st;
     ns.status = ST_RUNNING;
     ns.nan_flag = 0;
+    ns.tiny = 0;
     ns.panic_code = 0;
     ns.iters = ns.pivots = ns.flips = 0;
     ns.lambda = 0.0;
