@@ -174,8 +174,15 @@ def main():
                 continue
             want = "k_price<"
             for kname, kv in pm["kernels"].items():
-                # k_price<T, MODE, NT>: MODE is the second template argument
-                if kname.startswith(want) and kname.split(",")[1].strip().rstrip(">") == ("1" if dual else "0"):
+                # k_price<T, MODE, NT> or k_price_wave<MODE>: pick the pricing kernel of this solver
+                mode = "1" if dual else "0"
+                if kname.startswith("k_price_wave<"):
+                    hit = kname[len("k_price_wave<"):].rstrip(">").strip() == mode
+                elif kname.startswith("k_price<"):
+                    hit = kname.split(",")[1].strip().rstrip(">") == mode
+                else:
+                    hit = False
+                if hit:
                     traffic = kv["hbm_bytes_per_launch"]
             if traffic is not None:
                 break
@@ -186,7 +193,7 @@ def main():
     if pk in prof:
         t_us = prof[pk]["avg_us"]
         ach = price_bytes / (t_us * 1e-6) / 1e9
-        roofline = {"kernel": "k_price<T,1>" if dual else "k_price<T,0>", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"kernel": "pricing pass (k_price_wave<%d> / k_price<T,%d,NT>)" % ((1, 1) if dual else (0, 0)), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "bytes_per_launch": price_bytes, "avg_us": round(t_us, 3)}
     cpu = None
