@@ -960,12 +960,27 @@ __device__ __forceinline__ RatioResult ratio_fold(const double *chunkmin, int nc
     return RatioResult{lambda, nb, side};
 }
 
+// 16-byte store of a rewritten row of B^-1.  NT (k_update2): non-temporal — the 8*m*ld bytes a pivot
+// rewrites are not read again before the next k_ftran2, and as ordinary stores they sit dirty in the
+// L2s until the end-of-kernel write-back (measured at C3: k_update2 19.3 -> 17.9 us, k_ftran2 +0.6).
+// The refactorisation kernels re-read their rows at once and keep ordinary stores.
+template <bool NT>
+__device__ __forceinline__ void store_row2(double2 *p, double2 v) {
+    if (NT) {
+        __builtin_nontemporal_store(v.x, &p->x);
+        __builtin_nontemporal_store(v.y, &p->y);
+    } else {
+        *p = v;
+    }
+}
+
 // rows [row0, row0+nrows) (nrows <= 4) of the eta update:
 // dst[i,:] = src[i,:] - (d_i/d_r) * src[r,:]   (i != r),   dst[r,:] = src[r,:] / alpha_r.
 // The (up to) four rows go through together: every thread keeps four independent 16-byte loads
 // in flight and re-uses its chunk of the pivot row for all of them.  dv[k] = d[row0+k] is loaded
 // by the caller ahead of time (it does not depend on the pivot row).
 constexpr int UPD_ROWS = 4;
+template <bool NT>
 __device__ __forceinline__ void eta_update_rows(const double *src, double *dst, int64_t m, int64_t ld, int64_t r,
                                                 const double dv[UPD_ROWS], double d_r, double alpha_r,
                                                 int64_t row0, int nrows, int tid) {
@@ -996,7 +1011,7 @@ __device__ __forceinline__ void eta_update_rows(const double *src, double *dst, 
                 o.x = fma(f[k], p.x, w[k].x);
                 o.y = fma(f[k], p.y, w[k].y);
             }
-            reinterpret_cast<double2 *>(dst + ii[k] * ld)[t] = o;
+            store_row2<NT>(reinterpret_cast<double2 *>(dst + ii[k] * ld) + t, o);
         }
     }
 }
@@ -1283,15 +1298,15 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                             o.x = fma(f, pr[u].x, wreg[k][u].x);
                             o.y = fma(f, pr[u].y, wreg[k][u].y);
                         }
-                        drow[t] = o;
+                        store_row2<true>(drow + t, o);
                     }
                 }
             } else {
-                eta_update_rows(src, dst, m, a.ld, r, dv, d_r, alpha_r, row0,
+                eta_update_rows<true>(src, dst, m, a.ld, r, dv, d_r, alpha_r, row0,
                                 a.rows_per_block < UPD_ROWS ? a.rows_per_block : UPD_ROWS, tid);
             }
             if (a.rows_per_block > UPD_ROWS)
-                eta_update_rows(src, dst, m, a.ld, r, dv2, d_r, alpha_r, row0 + UPD_ROWS, a.rows_per_block - UPD_ROWS, tid);
+                eta_update_rows<true>(src, dst, m, a.ld, r, dv2, d_r, alpha_r, row0 + UPD_ROWS, a.rows_per_block - UPD_ROWS, tid);
         }
     }
     STAMP(2, 3);
@@ -1627,7 +1642,7 @@ __global__ __launch_bounds__(256) void k_ref_update(RefArgs a) {
     double dv[UPD_ROWS];
 #pragma unroll
     for (int k = 0; k < UPD_ROWS; ++k) dv[k] = (k < a.rows_per_block && row0 + k < a.m) ? a.d[row0 + k] : 0.0;
-    eta_update_rows(src, dst, a.m, a.ld, st->r, dv, st->d_r, st->alpha_r, row0, a.rows_per_block, threadIdx.x);
+    eta_update_rows<false>(src, dst, a.m, a.ld, st->r, dv, st->d_r, st->alpha_r, row0, a.rows_per_block, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_ref_permute(RefArgs a) {
