@@ -21,7 +21,8 @@
 //   u, d, x, c_B, c_N, keys, lambda_i : vectors.
 //
 // Launch structure — three launches per simplex iteration:
-//   primal:  k_price<.,0>   r = c_N - A_N^T u, Dantzig keys, per-block maxima      (HBM-bound)
+//   primal:  k_price<.,0>   r = c_N - A_N^T u, Dantzig keys, per-block maxima      (HBM-bound;
+//                           k_price_wave<0> when A_N is cache-resident)
 //            k_ftran2<0>    [entering fold] + d = +-B^-1 a_q + lambda_i per row    (HBM-bound)
 //            k_update2<0>   [ratio-test fold] + eta update of B^-1 + bookkeeping   (HBM-bound)
 //   dual:    k_price<.,1>   alpha = A_N^T rho, ratios d_j/alpha_j, per-block argmin
@@ -32,8 +33,10 @@
 // following bandwidth kernel recomputes the same fold in its prologue from inputs that no block
 // of that kernel writes (deterministic => all blocks agree), and block 0 alone commits the
 // decision to the state for later kernels.  Rule kept throughout: a kernel never reads a state
-// field that one of its own blocks writes (except `status`, where a late reader that sees the
-// final status simply exits — the result it would have produced is unused).
+// field that one of its own blocks writes (except `status`, where a late reader that sees a
+// FINAL status simply exits — the result it would have produced is unused; the one non-final
+// status, ST_NEED_MAINT, is for that reason never written by the kernel whose blocks must all
+// finish: see the comment at its definition).
 //
 // There is no CPU path in this file: without a HIP device every entry point returns
 // ELLP_ERR_DEVICE.
