@@ -106,6 +106,8 @@ def lib():
     L.ellp_engine_poll.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t]
     L.ellp_engine_rephase.restype = C.c_int
     L.ellp_engine_rephase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_hip_qr_transposed.restype = C.c_int
+    L.ellp_hip_qr_transposed.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     L.ellp_comm_unique_id.restype = C.c_int
     L.ellp_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
     L.ellp_engine_comm_init.restype = C.c_int
@@ -114,6 +116,21 @@ def lib():
     L.ellp_engine_run_sharded.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats), C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def qr_transposed(A, device=-1):
+    """Column-pivoted Householder QR of A^T on the device (standard_form.rs:142).  A: (m, nv) array.
+    Returns (pivots, |R_ii|), both of length min(m, nv)."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    m, nv = A.shape
+    mn = min(m, nv)
+    piv = np.zeros(mn, dtype=np.int64)
+    rd = np.zeros(mn, dtype=np.float64)
+    err = C.create_string_buffer(512)
+    s = lib().ellp_hip_qr_transposed(m, nv, A.ctypes.data_as(C.c_void_p), _p(piv), _p(rd), int(device), err, 512)
+    if s != OPTIMAL:
+        raise EllpHipError(s, err.value.decode())
+    return piv, rd
 
 
 def comm_unique_id(rccl_path=None):

@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 
-ENGINE_SRC = [os.path.join(HERE, "csrc", "engine", "ellp_engine.hip")]
+ENGINE_SRC = [os.path.join(HERE, "csrc", "engine", "ellp_engine.hip"),
+              os.path.join(HERE, "csrc", "engine", "ellp_qr.hip")]
 ENGINE_LIB = os.path.join(HERE, "libellp_hip.so")
 HOST_DIR = os.path.join(HERE, "csrc", "host")
 HOST_LIB = os.path.join(HERE, "libellp_host.so")

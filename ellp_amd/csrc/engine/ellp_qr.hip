@@ -1,0 +1,277 @@
+// ellp_qr.hip — column-pivoted Householder QR of A^T on the device.
+//
+// The reference's standard form runs `A.transpose().col_piv_qr()` (src/standard_form.rs:142) to
+// detect redundant rows; all it consumes is the column transposition list and |R_ii|
+// (:143-181).  On one host core that is ~2*n*m^2 flop — about a minute at m=2000, n=7000 and a
+// quarter of an hour at config 5 — while the simplex loop itself takes seconds on the GPU.
+//
+// This is the same algorithm as ellp_amd/csrc/host/dense.h ColPivQR / oracle col_piv_qr (pivot =
+// column holding the entry of maximal modulus of the trailing block, first such entry in
+// column-major order; Householder reflector with nalgebra's normalisation), arranged so that
+// every floating-point result is BITWISE what the host loop produces: each dot product and
+// each norm is accumulated by ONE thread in the host's order (r ascending, multiply then add,
+// compiled with -ffp-contract=off).  Parallelism comes from the independent columns (one
+// thread per column, coalesced because M = A^T is walked through A's own column-major storage:
+// M[r, j] = A[j + r*m]) and from the element-wise passes.  Not bandwidth-optimal — it does not
+// need to be: 4 launches per elimination step (tools/qr_time.py for timings).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ellp_hip.h"
+
+namespace {
+
+struct QrState {
+    int64_t pj;       // pivot column of the current step
+    int32_t skip;     // factor == 0: no reflector to apply (dense.h: `continue`)
+    int32_t pad;
+};
+
+// per-column candidate for the next pivot search: cand[j] = max_r |M[r, j]| over the trailing rows
+// (the first such r wins inside the column, but only the column matters for the pivot)
+__global__ __launch_bounds__(256) void k_qr_scan(const double *A, int64_t m, int64_t nv, int64_t i, double *cand) {
+    const int64_t j = i + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    double best = -1.0;
+    for (int64_t r = i; r < nv; ++r) {
+        const double v = fabs(A[j + r * m]);
+        if (v > best) best = v;
+    }
+    cand[j] = best;
+}
+
+// every block: pj = first column (lowest j >= i) holding the maximal candidate — host order is
+// j ascending then r ascending with a strict '>', and the initial value |M[i,i]| belongs to
+// column i, so the lowest j among the maxima wins.  Then the block swaps its slice of columns
+// i and pj of M (rows i, pj of A) and copies the pivot column's trailing part to xbuf.
+__global__ __launch_bounds__(256) void k_qr_swap(double *A, int64_t m, int64_t nv, int64_t i, const double *cand,
+                                                 double *xbuf, QrState *st, int64_t *pivot_out) {
+    __shared__ double s_v[4];
+    __shared__ long long s_j[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double bv = -1.0;
+    long long bj = -1;
+    for (int64_t j = i + tid; j < m; j += 256) {
+        const double v = cand[j];
+        if (bj < 0 || v > bv) {  // this thread's j ascend: strict '>' keeps its lowest j
+            bv = v;
+            bj = j;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o);
+        const long long oj = __shfl_xor(bj, o);
+        if (oj >= 0 && (bj < 0 || ov > bv || (ov == bv && oj < bj))) {
+            bv = ov;
+            bj = oj;
+        }
+    }
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_j[wave] = bj;
+    }
+    __syncthreads();
+    bv = s_v[0];
+    bj = s_j[0];
+    for (int w = 1; w < 4; ++w)
+        if (s_j[w] >= 0 && (bj < 0 || s_v[w] > bv || (s_v[w] == bv && s_j[w] < bj))) {
+            bv = s_v[w];
+            bj = s_j[w];
+        }
+    const int64_t pj = bj;
+    if (blockIdx.x == 0 && tid == 0) {
+        st->pj = pj;
+        pivot_out[i] = pj;
+    }
+    const int64_t r = (int64_t)blockIdx.x * 256 + tid;
+    if (r < nv) {
+        double a = A[i + r * m];
+        if (pj != i) {
+            const double b = A[pj + r * m];
+            A[pj + r * m] = a;
+            A[i + r * m] = b;
+            a = b;
+        }
+        if (r >= i) xbuf[r - i] = a;
+    }
+}
+
+// the reflector of dense.h ColPivQR: the two norms are accumulated by thread 0 in the host's order
+// (from LDS, which the whole block fills chunk by chunk — a single thread reading global memory
+// pays a full round trip per element), the element-wise divisions by all threads
+constexpr int XCHUNK = 4096;
+__device__ __forceinline__ double sequential_sumsq(const double *x, int64_t len, double *s_x, double *s_out) {
+    const int tid = threadIdx.x;
+    double acc = 0.0;  // meaningful in thread 0
+    for (int64_t c0 = 0; c0 < len; c0 += XCHUNK) {
+        const int64_t n = (len - c0) < XCHUNK ? (len - c0) : XCHUNK;
+        for (int64_t k = tid; k < n; k += 256) s_x[k] = x[c0 + k];
+        __syncthreads();
+        if (tid == 0)
+            for (int64_t k = 0; k < n; ++k) acc += s_x[k] * s_x[k];
+        __syncthreads();
+    }
+    if (tid == 0) *s_out = acc;
+    __syncthreads();
+    return *s_out;
+}
+
+__global__ __launch_bounds__(256) void k_qr_reflect(double *xbuf, int64_t len, int64_t i, QrState *st, double *rdiag) {
+    __shared__ double s_x[XCHUNK];
+    __shared__ double s_sum, s_sf;
+    __shared__ int s_skip;
+    const int tid = threadIdx.x;
+    const double sqn = sequential_sumsq(xbuf, len, s_x, &s_sum);
+    if (tid == 0) {
+        const double norm = sqrt(sqn);
+        const double x0 = xbuf[0];
+        const double signed_norm = (x0 < 0.0) ? -norm : norm;
+        const double factor = (sqn + fabs(x0) * norm) * 2.0;
+        rdiag[i] = norm;
+        xbuf[0] = x0 + signed_norm;
+        s_skip = factor == 0.0 ? 1 : 0;
+        s_sf = sqrt(factor);
+        st->skip = s_skip;
+    }
+    __syncthreads();
+    if (s_skip) return;
+    const double sf = s_sf;
+    for (int64_t r = tid; r < len; r += 256) xbuf[r] = xbuf[r] / sf;
+    __syncthreads();
+    const double n2 = sqrt(sequential_sumsq(xbuf, len, s_x, &s_sum));
+    if (n2 != 0.0)
+        for (int64_t r = tid; r < len; r += 256) xbuf[r] = xbuf[r] / n2;
+}
+
+// dot[j] = sum_r x[r] * M[i + r, j], one thread per trailing column j > i, accumulated in the host's
+// order; the loads of 32 consecutive rows are issued together so that the sequential chain of adds
+// is not also a chain of memory round trips.  Writes f2[j] = -2 * dot and clears the column's
+// pivot-search candidate for k_qr_update.
+constexpr int DOTB = 32;
+__global__ __launch_bounds__(64) void k_qr_dot(const double *A, int64_t m, int64_t nv, int64_t i, const double *xbuf,
+                                               const QrState *st, double *f2, double *cand) {
+    const int64_t j = i + 1 + (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= m) return;
+    cand[j] = 0.0;
+    if (st->skip) {
+        f2[j] = 0.0;
+        return;
+    }
+    const int64_t len = nv - i;
+    const double *cj = A + j + i * m;  // M[i + r, j] = cj[r * m]
+    double dot = 0.0;
+    int64_t r0 = 0;
+    for (; r0 + DOTB <= len; r0 += DOTB) {
+        double v[DOTB], xv[DOTB];
+#pragma unroll
+        for (int k = 0; k < DOTB; ++k) {
+            v[k] = cj[(r0 + k) * m];
+            xv[k] = xbuf[r0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < DOTB; ++k) dot += xv[k] * v[k];
+    }
+    for (; r0 < len; ++r0) dot += xbuf[r0] * cj[r0 * m];
+    f2[j] = -2.0 * dot;
+}
+
+// M[i + r, j] = f2[j] * x[r] + M[i + r, j] over the whole trailing block (element-wise: any order),
+// and the per-column maximum of |.| over rows i+1.. for the next pivot search (a maximum is exact in
+// any order too: atomicMax on the bit pattern of a non-negative double)
+constexpr int UPD_R = 64;
+__global__ __launch_bounds__(256) void k_qr_update(double *A, int64_t m, int64_t nv, int64_t i, const double *xbuf,
+                                                   const QrState *st, const double *f2, double *cand) {
+    const int64_t j = i + 1 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t len = nv - i;
+    const int64_t r0 = (int64_t)blockIdx.y * UPD_R;
+    const int64_t r1 = (r0 + UPD_R < len) ? r0 + UPD_R : len;
+    double *cj = A + j + i * m;
+    const bool skip = st->skip != 0;
+    const double f = f2[j];
+    double best = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+        double v = cj[r * m];
+        if (!skip) {
+            v = f * xbuf[r] + v;
+            cj[r * m] = v;
+        }
+        if (r > 0) best = fmax(best, fabs(v));
+    }
+    if (best > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long *>(cand + j), (unsigned long long)__double_as_longlong(best));
+}
+
+void set_err(char *errbuf, size_t len, const char *msg, hipError_t e) {
+    if (errbuf && len) snprintf(errbuf, len, "%s: %s", msg, hipGetErrorString(e));
+}
+
+}  // namespace
+
+extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out,
+                                              double *rdiag_out, int device, char *errbuf, size_t errlen) {
+    if (errbuf && errlen) errbuf[0] = 0;
+    if (m < 0 || nv < 0 || (m > 0 && nv > 0 && (!A || !pivot_out || !rdiag_out))) return ELLP_ERR_ARG;
+    const int64_t mn = m < nv ? m : nv;
+    if (mn == 0) return ELLP_OPTIMAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        if (errbuf && errlen) snprintf(errbuf, errlen, "no HIP device available");
+        return ELLP_ERR_DEVICE;
+    }
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return ELLP_ERR_DEVICE;
+    double *dA = nullptr, *xbuf = nullptr, *cand = nullptr, *rdiag = nullptr, *f2 = nullptr;
+    int64_t *piv = nullptr;
+    QrState *st = nullptr;
+    hipStream_t stream = nullptr;
+    hipError_t rc = hipSuccess;
+    auto cleanup = [&] {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        (void)hipFree(dA); (void)hipFree(xbuf); (void)hipFree(cand); (void)hipFree(rdiag); (void)hipFree(f2); (void)hipFree(piv); (void)hipFree(st);
+    };
+#define QCHK(expr)                                      \
+    do {                                                \
+        rc = (expr);                                    \
+        if (rc != hipSuccess) {                         \
+            set_err(errbuf, errlen, #expr, rc);         \
+            cleanup();                                  \
+            return ELLP_ERR_DEVICE;                     \
+        }                                               \
+    } while (0)
+    QCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&dA), sizeof(double) * (size_t)(m * nv)));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&xbuf), sizeof(double) * (size_t)nv));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&cand), sizeof(double) * (size_t)m));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&f2), sizeof(double) * (size_t)m));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&rdiag), sizeof(double) * (size_t)mn));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&piv), sizeof(int64_t) * (size_t)mn));
+    QCHK(hipMalloc(reinterpret_cast<void **>(&st), sizeof(QrState)));
+    QCHK(hipMemcpyAsync(dA, A, sizeof(double) * (size_t)(m * nv), hipMemcpyHostToDevice, stream));
+    QCHK(hipMemsetAsync(st, 0, sizeof(QrState), stream));
+    hipLaunchKernelGGL(k_qr_scan, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, dA, m, nv, (int64_t)0, cand);
+    for (int64_t i = 0; i < mn; ++i) {
+        hipLaunchKernelGGL(k_qr_swap, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, dA, m, nv, i, cand, xbuf,
+                           st, piv);
+        hipLaunchKernelGGL(k_qr_reflect, dim3(1), dim3(256), 0, stream, xbuf, nv - i, i, st, rdiag);
+        if (i + 1 < m) {
+            const int64_t ncol = m - i - 1, len = nv - i;
+            hipLaunchKernelGGL(k_qr_dot, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, stream, dA, m, nv, i, xbuf, st,
+                               f2, cand);
+            hipLaunchKernelGGL(k_qr_update, dim3((unsigned)((ncol + 255) / 256), (unsigned)((len + UPD_R - 1) / UPD_R)),
+                               dim3(256), 0, stream, dA, m, nv, i, xbuf, st, f2, cand);
+        }
+    }
+    QCHK(hipGetLastError());
+    QCHK(hipMemcpyAsync(pivot_out, piv, sizeof(int64_t) * (size_t)mn, hipMemcpyDeviceToHost, stream));
+    QCHK(hipMemcpyAsync(rdiag_out, rdiag, sizeof(double) * (size_t)mn, hipMemcpyDeviceToHost, stream));
+    QCHK(hipStreamSynchronize(stream));
+#undef QCHK
+    cleanup();
+    return ELLP_OPTIMAL;
+}

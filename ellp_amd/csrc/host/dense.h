@@ -191,6 +191,7 @@ private:
 struct ColPivQR {
     PermutationSequence p;
     std::vector<double> r_diag_abs;
+    ColPivQR() = default;  // filled by the device path (problem.cpp: col_piv_qr_of_transpose)
     explicit ColPivQR(Matrix m) {
         const Index mn = std::min(m.rows, m.cols);
         r_diag_abs.assign(static_cast<size_t>(mn), 0.0);

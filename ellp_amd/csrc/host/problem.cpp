@@ -1,11 +1,44 @@
 // problem.cpp — Problem builder + StandardForm (src/problem.rs, src/standard_form.rs).
 #include <cmath>
+#include <cstdlib>
 #include <sstream>
+#include <stdexcept>
 #include <unordered_map>
 
 #include "ellp.h"
 
 namespace ellp {
+
+namespace {
+
+using dense::Index;
+
+// `A.transpose().col_piv_qr()` (standard_form.rs:142).  Large matrices go to the device
+// (ellp_hip_qr_transposed: the same arithmetic, bitwise — ~2 n m^2 flop are a minute of one host
+// core at m=2000, n=7000); small ones, and any matrix when no HIP device is present, use the host
+// loop.  ELLP_QR_DEVICE=1 / 0 forces the choice (tests).
+dense::ColPivQR col_piv_qr_of_transpose(const dense::Matrix &A) {
+    const char *force = std::getenv("ELLP_QR_DEVICE");
+    const bool want_device = force ? force[0] == '1' : (A.rows * A.cols >= (Index)1 << 20);
+    if (want_device && !A.is_empty()) {
+        const Index mn = std::min(A.rows, A.cols);
+        std::vector<std::int64_t> piv(static_cast<size_t>(mn));
+        dense::ColPivQR qr;
+        qr.r_diag_abs.assign(static_cast<size_t>(mn), 0.0);
+        char err[256] = {0};
+        const ellp_status s = ellp_hip_qr_transposed(static_cast<std::int64_t>(A.rows), static_cast<std::int64_t>(A.cols),
+                                                     A.a.data(), piv.data(), qr.r_diag_abs.data(), -1, err, sizeof(err));
+        if (s == ELLP_OPTIMAL) {
+            for (Index i = 0; i < mn; ++i) qr.p.append_permutation(i, static_cast<Index>(piv[static_cast<size_t>(i)]));
+            return qr;
+        }
+        if (force && force[0] == '1') throw std::runtime_error(std::string("device QR failed: ") + err);
+    }
+    return dense::ColPivQR(A.transpose());
+}
+
+}  // namespace
+
 
 using dense::Index;
 
@@ -144,7 +177,7 @@ std::optional<StandardForm> StandardForm::from_problem(Problem prob) {
     }
 
     // remove redundant rows (:142-181)
-    dense::ColPivQR qr(A.transpose());
+    dense::ColPivQR qr = col_piv_qr_of_transpose(A);
     const Index r_rows = std::min(total_vars, m);
     std::vector<double> &rd = qr.r_diag_abs;
     qr.p.inv_permute_rows(b);

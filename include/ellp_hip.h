@@ -237,6 +237,17 @@ double ellp_engine_inverse_residual(ellp_engine *e);
 
 void ellp_engine_destroy(ellp_engine *e);
 
+/*
+ * SURVEY.md §8 f3 — the rank check of the standard form on the device: column-pivoted Householder
+ * QR of A^T (src/standard_form.rs:142 `A.transpose().col_piv_qr()`), reduced to what :143-181
+ * consume.  A: m x nv column-major (ld = m) in HOST memory, not modified.  pivot_out[i] = the
+ * column of A^T (row of A) swapped into position i at step i (the transposition list),
+ * rdiag_out[i] = |R_ii|, both of length min(m, nv).  Every floating-point result is bitwise what the
+ * host loop of ellp_amd/csrc/host/dense.h (ColPivQR) produces.  device < 0: current device.
+ */
+ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out, double *rdiag_out,
+                                   int device, char *errbuf, size_t errbuf_len);
+
 #ifdef __cplusplus
 }
 #endif

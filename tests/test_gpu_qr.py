@@ -1,0 +1,145 @@
+"""the standard form's rank check (`A.transpose().col_piv_qr()`,
+standard_form.rs:142) on the device.  Bar: bitwise the host loop's pivots and |R_ii| — so the
+standard form, and everything downstream, is identical whichever side computed the QR."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, known_answers
+
+pytestmark = pytest.mark.gpu
+KA = known_answers()
+
+
+def host_col_piv_qr_of_transpose(A):
+    """Plain restatement of ellp_amd/csrc/host/dense.h ColPivQR (= oracle col_piv_qr) on M = A^T,
+    every sum sequential in the same order."""
+    M = np.array(A.T, dtype=np.float64, order="F")
+    rows, cols = M.shape
+    mn = min(rows, cols)
+    piv, rd = [], []
+    for i in range(mn):
+        pj, best = i, abs(M[i, i])
+        for j in range(i, cols):
+            for r in range(i, rows):
+                v = abs(M[r, j])
+                if v > best:
+                    best, pj = v, j
+        if pj != i:
+            M[:, [i, pj]] = M[:, [pj, i]]
+        piv.append(pj)
+        x = M[i:, i]
+        sqn = 0.0
+        for v in x:
+            sqn += v * v
+        norm = np.sqrt(sqn)
+        signed_norm = -norm if x[0] < 0.0 else norm
+        factor = (sqn + abs(x[0]) * norm) * 2.0
+        rd.append(norm)
+        x[0] += signed_norm
+        if factor == 0.0:
+            continue
+        sf = np.sqrt(factor)
+        n2 = 0.0
+        for r in range(len(x)):
+            x[r] /= sf
+            n2 += x[r] * x[r]
+        n2 = np.sqrt(n2)
+        if n2 != 0.0:
+            for r in range(len(x)):
+                x[r] /= n2
+        for j in range(i + 1, cols):
+            cj = M[i:, j]
+            dot = 0.0
+            for r in range(len(x)):
+                dot += x[r] * cj[r]
+            f2 = -2.0 * dot
+            for r in range(len(x)):
+                cj[r] = f2 * x[r] + cj[r]
+    return np.array(piv, dtype=np.int64), np.array(rd)
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    yield "wide", rng.uniform(-1, 1, size=(7, 19))
+    yield "tall", rng.uniform(-1, 1, size=(15, 6))          # more rows than variables
+    yield "square", rng.uniform(-1, 1, size=(9, 9))
+    A = rng.integers(-2, 3, size=(8, 14)).astype(float)      # many exact ties
+    yield "ties", A
+    A = rng.uniform(-1, 1, size=(8, 12))
+    A[5] = A[2]                                               # a redundant row
+    A[6] = 2.0 * A[1] - A[3]
+    yield "rank-deficient", A
+    A = rng.uniform(-1, 1, size=(6, 10))
+    A[3] = 0.0                                                # a zero row: factor == 0 at the end
+    A[4] = 0.0
+    yield "zero-rows", A
+    yield "one-row", rng.uniform(-1, 1, size=(1, 5))
+    yield "one-col", rng.uniform(-1, 1, size=(5, 1))
+
+
+@pytest.mark.parametrize("name,A", list(_cases()), ids=[n for n, _ in _cases()])
+def test_device_qr_is_bitwise_the_host_loop(name, A):
+    from ellp_amd import _engine as E
+    piv_d, rd_d = E.qr_transposed(A)
+    piv_h, rd_h = host_col_piv_qr_of_transpose(A)
+    np.testing.assert_array_equal(piv_d, piv_h)
+    np.testing.assert_array_equal(rd_d, rd_h)  # bitwise
+
+
+def _phase1_arrays(prob, solver):
+    ph = prob._debug_phase1(solver)
+    return None if ph is None else {k: np.array(v) if hasattr(v, "__len__") else v for k, v in ph.items()}
+
+
+@pytest.mark.parametrize("solver", ["primal", "dual"])
+def test_standard_form_is_identical_with_device_qr(solver):
+    """Every fixture and netlib problem: the phase-1 arrays built on top of the standard form are the
+    same whether the QR ran on the host or on the device."""
+    from ellp_amd import Problem, parse_mps
+    probs = [(fx["name"], lambda fx=fx: Problem.from_fixture(fx)) for fx in KA["problems"]]
+    probs += [(fx["name"], lambda fx=fx: parse_mps(open(os.path.join(GOLDEN, fx["file"])).read())) for fx in KA["netlib"]]
+    old = os.environ.get("ELLP_QR_DEVICE")
+    try:
+        for name, make in probs:
+            os.environ["ELLP_QR_DEVICE"] = "0"
+            a = _phase1_arrays(make(), solver)
+            os.environ["ELLP_QR_DEVICE"] = "1"
+            b = _phase1_arrays(make(), solver)
+            assert (a is None) == (b is None), name
+            if a is None:
+                continue
+            assert a.keys() == b.keys()
+            for k in a:
+                if isinstance(a[k], np.ndarray):
+                    np.testing.assert_array_equal(a[k], b[k], err_msg=f"{name}:{k}")
+                else:
+                    assert a[k] == b[k], (name, k)
+    finally:
+        if old is None:
+            os.environ.pop("ELLP_QR_DEVICE", None)
+        else:
+            os.environ["ELLP_QR_DEVICE"] = old
+
+
+def test_full_api_solve_of_a_mid_size_dense_lp_uses_the_device_qr():
+    """m=600, n=1500 through Problem -> solver.solve(): above the size threshold the standard form's
+    QR runs on the device; the optimum must match the oracle's objective for the same LP solved from
+    the directly built phase arrays (which skip the QR: full row rank keeps the rows in order)."""
+    import time
+    from ellp_amd import Bound, ConstraintOp, PrimalSimplexSolver, Problem, synth
+    m, n = 600, 1500
+    A, b, c = synth.dense_lp(20260301, m, n)
+    p = Problem()
+    ids = [p.add_var(float(c[j]), Bound.Lower(0.0)) for j in range(n)]
+    for i in range(m):
+        p.add_constraint([(ids[j], float(A[i, j])) for j in range(n)], ConstraintOp.Lte, float(b[i]))
+    t0 = time.time()
+    res = PrimalSimplexSolver.new(None).solve(p)
+    dt = time.time() - t0
+    assert res.kind == "optimal"
+    from scipy.optimize import linprog
+    ref = linprog(c, A_ub=A, b_ub=b, bounds=[(0, None)] * n, method="highs")
+    assert abs(res.solution.obj() - ref.fun) < 1e-7 * (1 + abs(ref.fun))
+    assert dt < 120
