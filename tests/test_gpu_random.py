@@ -44,6 +44,38 @@ def random_fixture(rng):
         cons.append([coeffs, op, rhs])
     return {"vars": vars_, "constraints": cons}
 
+def feasible_fixture(rng):
+    """Feasible and bounded by construction (so both phases run to an optimum): box-bounded or fixed
+    variables, right-hand sides built from a point x0 inside the bounds, with exact-tie-prone integer
+    data half of the time and a few redundant (duplicated / combined) rows."""
+    m = int(rng.integers(2, 16)); n = int(rng.integers(2, 20))
+    integer = rng.random() < 0.5
+    vars_, x0 = [], []
+    for j in range(n):
+        c = float(rng.integers(-4, 5)) if integer else float(rng.normal())
+        lo = float(rng.integers(-3, 3)) if integer else float(rng.normal())
+        w = float(rng.integers(1, 5)) if integer else float(abs(rng.normal()) + 0.1)
+        if rng.random() < 0.1:
+            vars_.append([c, ["Fixed", lo, lo]]); x0.append(lo)
+        else:
+            vars_.append([c, ["TwoSided", lo, lo + w]])
+            x0.append(lo + (float(rng.integers(0, int(w) + 1)) if integer else float(rng.random() * w)))
+    rows = []
+    for i in range(m):
+        a = np.where(rng.random(n) < 0.7, rng.integers(-3, 4, size=n).astype(float) if integer else rng.normal(size=n), 0.0)
+        rows.append(a)
+    if m >= 3 and rng.random() < 0.4:
+        rows[m - 1] = rows[0] + rows[1]            # a redundant equality candidate
+    cons = []
+    for i, a in enumerate(rows):
+        ax = float(np.dot(a, x0))
+        op = str(rng.choice(["Lte", "Gte", "Eq"], p=[0.4, 0.3, 0.3]))
+        slack = float(rng.integers(0, 4)) if integer else float(abs(rng.normal()))
+        rhs = ax + slack if op == "Lte" else (ax - slack if op == "Gte" else ax)
+        cons.append([[[j, float(a[j])] for j in range(n) if a[j] != 0.0], op, rhs])
+    return {"vars": vars_, "constraints": cons}
+
+
 def flat(v):
     return _E().FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B, v.N[:v.nN], v.Nb[:v.nN], v.y, v.d)
 
@@ -72,11 +104,12 @@ def compare(tag, ov, st_o, it_o, fp, st_g, stats, err_o, err_g, out):
 
 
 
-def _campaign(seed0, count):
+def _campaign(seed0, count, make=None):
+    make = make or random_fixture
     bad = []
     n = {"primal": 0, "dual": 0}
     for s in range(seed0, seed0 + count):
-        fx = random_fixture(np.random.default_rng(s))
+        fx = make(np.random.default_rng(s))
         prob = eo.Problem.from_fixture(fx)
         p1, err = eo.primal_phase1(prob)
         if p1 is not None and not err:
@@ -93,7 +126,7 @@ def _campaign(seed0, count):
         d1, err = eo.dual_phase1(prob)
         if d1 is not None and not err:
             v1 = d1.view()
-            if v1.m > 0 and v1.nN > 0:
+            if v1.m > 0:  # nN == 0 (every variable boxed): Optimal at once (dual…:175-177), then phase 2
                 n["dual"] += 1
                 r = seam(v1, "dual")
                 ok = compare((s, "dual1"), *r, bad)
@@ -103,7 +136,7 @@ def _campaign(seed0, count):
                     d2, err2 = eo.dual_phase2(d1)
                     if d2 is not None and not err2:
                         v2 = d2.view()
-                        if v2.m > 0 and v2.nN > 0:
+                        if v2.m > 0:
                             compare((s, "dual2"), *seam(v2, "dual"), bad)
     return n, bad
 
@@ -118,3 +151,59 @@ def test_random_lps_primal_exact_dual_same_objective():
     dual_paths = [b for b in bad if b[0][1].startswith("dual")]
     assert all(b[4] < 1e-8 for b in dual_paths), dual_paths[:5]      # same objective on a tie-broken path
     assert len(dual_paths) <= 0.03 * n["dual"], (len(dual_paths), n["dual"])
+
+
+def test_random_feasible_bounded_lps_both_phases():
+    """The same checks on LPs that are feasible and bounded by construction, so that phase 2 runs too
+    (most purely random LPs end infeasible or unbounded in phase 1)."""
+    n, bad = _campaign(7000, 300, feasible_fixture)
+    assert n["primal"] > 250 and n["dual"] > 200
+    # Quirk Q1 (primal…:359 + assert :402) makes the reference itself rounding-fragile on box-bounded
+    # LPs: a TwoSided basic that sits ON its lower bound up to the last bit gives lambda_i = (lb - x)/d
+    # = -1e-16/|d| when x is one ulp below, and the reference then panics "lambda >= 0."; with x one
+    # ulp the other way it carries on.  Oracle and engine round the FTRAN differently (LU solve vs
+    # B^-1 a_q), so they can fall on different sides (seeds 7140, 7184: x differs by 5e-16).  Such
+    # cases are set aside and must stay rare; everything else must agree as above.
+    fragile = [b for b in bad if b[1] == "status" and ("lambda >= 0" in str(b[4]) or "lambda >= 0" in str(b[5]))]
+    assert len(fragile) <= 0.03 * n["primal"], fragile
+    bad = [b for b in bad if b not in fragile]
+    hard = [b for b in bad if b[1] != "path"]
+    assert not hard, hard[:5]
+    primal_paths = [b for b in bad if b[0][1].startswith("primal")]
+    assert not primal_paths, primal_paths[:5]
+    dual_paths = [b for b in bad if b[0][1].startswith("dual")]
+    assert all(b[4] < 1e-8 for b in dual_paths), dual_paths[:5]
+    assert len(dual_paths) <= 0.05 * n["dual"], (len(dual_paths), n["dual"])
+
+
+def test_random_lps_end_to_end_through_the_host_mirror():
+    """solver.solve(problem) (C++ host mirror + GPU loops, resident two-phase primal) against the oracle's
+    solve() on 300 random and 200 feasible LPs, both solvers: same outcome (a reference panic shows up
+    as an exception), same objective."""
+    from ellp_amd import DualSimplexSolver, PrimalSimplexSolver, Problem
+    cases = [random_fixture(np.random.default_rng(s)) for s in range(5000, 5300)]
+    cases += [feasible_fixture(np.random.default_rng(s)) for s in range(9000, 9200)]
+    n_opt = n_fragile = 0
+    for k, fx in enumerate(cases):
+        for name, S in (("primal", PrimalSimplexSolver), ("dual", DualSimplexSolver)):
+            o = eo.solve(eo.Problem.from_fixture(fx), name)
+            try:
+                r = S.default().solve(Problem.from_fixture(fx))
+                got = r.kind
+            except Exception as e:  # EllPError / panic of the reference
+                got = "raised"
+            if o.status < 0:
+                if "lambda >= 0" in o.err:  # quirk Q1 fragility, see above: either outcome is the reference's
+                    n_fragile += 1
+                    continue
+                assert got == "raised", (k, name, o.status, o.err, got)
+                continue
+            if got == "raised" and name == "primal":
+                n_fragile += 1  # the engine fell on the panicking side of the same quirk
+                continue
+            assert got == eo.STATUS_NAME[o.status], (k, name, eo.STATUS_NAME[o.status], got)
+            if got == "optimal":
+                n_opt += 1
+                assert abs(r.solution.obj() - o.obj) <= 1e-8 * (1 + abs(o.obj)), (k, name, r.solution.obj(), o.obj)
+    assert n_opt > 120  # the reference reports many of the constructed LPs infeasible (quirk Q7) or panics in dual phase 2
+    assert n_fragile <= 15, n_fragile
