@@ -548,7 +548,9 @@ __device__ __forceinline__ long long entering_fold_full(const double *s_bk, int 
         const double bm = (g0 + lane < nblocks) ? s_bk[g0 + lane] : -INFINITY;
         int from = 0;
         for (;;) {
-            const bool pred = lane >= from && bm > -INFINITY && (!f.have || bm > f.racc - eps);
+            // a block matters iff it may hold a key with racc - key < EPS.  Written as a DIFFERENCE: racc - EPS
+            // is absorbed once racc exceeds ~4e6 (ulp > EPS) and `bm > racc - eps` would then skip bm == racc
+            const bool pred = lane >= from && bm > -INFINITY && (!f.have || f.racc - bm < eps);
             const unsigned long long mask = __ballot(pred);
             if (!mask) break;
             const int bl = __ffsll((long long)mask) - 1;
@@ -688,10 +690,12 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         // H = blocks within 4 EPS of the maximum; band = blocks in the next 2 EPS
         for (int b = tid; b < a.nblocks; b += 256) {
             const double v = s_bk[b];
-            if (v > M - 4.0 * a.eps) {
+            // distances from the maximum, never M - 4 EPS itself: for keys above ~4e6 that expression is
+            // absorbed (M - 4e-10 == M), no block would qualify and the fold would report "no candidate"
+            if (M - v < 4.0 * a.eps) {
                 const int slot = atomicAdd(&s_nh, 1);
                 if (slot < FC_SLOTS) s_hblk[slot] = b;
-            } else if (v > M - 6.0 * a.eps) {
+            } else if (M - v < 6.0 * a.eps) {
                 s_band = 1;
             }
         }
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
                 const double kv = ok ? kl : -INFINITY;
                 s_hkey[sl * 64 + lane] = kv;
                 s_hidx[sl * 64 + lane] = ok ? (int32_t)il : 0;
-                if (kv > M - 6.0 * a.eps && !(kv > M - 4.0 * a.eps)) s_band = 1;  // an element in the gap
+                if (M - kv < 6.0 * a.eps && !(M - kv < 4.0 * a.eps)) s_band = 1;  // an element in the gap
             }
             lds_barrier();
         }
@@ -931,7 +935,9 @@ __device__ __forceinline__ RatioResult ratio_fold(const double *chunkmin, int nc
         const double cm = (g0 + lane < nchunks) ? chunkmin[g0 + lane] : INFINITY;
         int from = 0;
         for (;;) {
-            const bool pred = lane >= from && cm < lambda + eps;
+            // skip a chunk only if every lambda_i in it is at least EPS above lambda (difference form:
+            // lambda + eps is absorbed for lambda above ~4e6 and a tie at lambda would be skipped)
+            const bool pred = lane >= from && !(cm - lambda >= eps);
             const unsigned long long mask = __ballot(pred);
             if (!mask) break;
             const int cl = __ffsll((long long)mask) - 1;

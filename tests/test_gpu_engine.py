@@ -245,3 +245,27 @@ def test_dual_synthetic_start(m, n):
     A, b, c = synth.covering_lp(20260301, m, n)
     h = linprog(c, A_ub=-A, b_ub=-b, bounds=(0, None), method="highs")
     assert abs(fp.obj() - h.fun) < 1e-8
+
+
+@pytest.mark.parametrize("scale", [1e7, 1e12])
+def test_primal_large_reduced_costs(scale):
+    """Keys far above 4e6: M - 4 EPS is absorbed in floating point (M - 4e-10 == M), so the folds' skip
+    tests must be written as differences.  (Found by the random campaign: with `key > M - 4 EPS` no
+    block qualified and the engine reported Optimal while keys of 8e6 were on the table.)  Costs scaled
+    by `scale`: phase 1 (unit costs) pivot for pivot, phase 2 to the same optimum as the oracle — at this
+    magnitude the rounding noise of a reduced cost exceeds the reference's absolute EPS band, so the
+    tie-breaks, and with them the pivot order, are not comparable any more."""
+    A, b, c = eo.synth_dense_lp(20260301, 50, 120)
+    fx = {"vars": [[float(c[j]) * scale, ["Lower", 0.0, 0.0]] for j in range(120)],
+          "constraints": [[[[j, float(A[i, j])] for j in range(120)], "Lte", float(b[i])] for i in range(50)]}
+    prob = eo.Problem.from_fixture(fx)
+    p1, err = eo.primal_phase1(prob)
+    ov, st_o, it_o, fp, st_g, stats, err_g = run_both(p1.view(), "primal", None)
+    assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis=True)
+    p1.store_point(ov)
+    p2 = eo.primal_phase2(p1)
+    ov2, st_o2, it_o2, fp2, st_g2, stats2, err_g2 = run_both(p2.view(), "primal", None)
+    assert st_g2 >= 0, err_g2
+    assert st_o2 == st_g2 == eo.OPTIMAL and it_o2 > 50 and stats2.iters > 50
+    assert abs(fp2.obj() - ov2.obj()) <= 1e-9 * abs(ov2.obj())
+    np.testing.assert_allclose(fp2.x, ov2.x, rtol=0, atol=1e-9 * (1 + np.abs(ov2.x).max()))
