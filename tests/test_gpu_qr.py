@@ -143,3 +143,43 @@ def test_full_api_solve_of_a_mid_size_dense_lp_uses_the_device_qr():
     ref = linprog(c, A_ub=A, b_ub=b, bounds=[(0, None)] * n, method="highs")
     assert abs(res.solution.obj() - ref.fun) < 1e-7 * (1 + abs(ref.fun))
     assert dt < 120
+
+
+def test_standard_form_identical_on_random_lps():
+    """300 random LPs (every operator and bound kind, integer data with exact ties, redundant rows):
+    the phase-1 arrays are identical whichever side ran the rank check."""
+    from ellp_amd import Problem
+    from test_gpu_random import feasible_fixture, random_fixture
+    cases = [random_fixture(np.random.default_rng(s)) for s in range(20000, 20150)]
+    cases += [feasible_fixture(np.random.default_rng(s)) for s in range(21000, 21150)]
+    old = os.environ.get("ELLP_QR_DEVICE")
+    n_cmp = 0
+    try:
+        for k, fx in enumerate(cases):
+            for solver in ("primal", "dual"):
+                out = []
+                for side in ("0", "1"):
+                    os.environ["ELLP_QR_DEVICE"] = side
+                    try:
+                        out.append(_phase1_arrays(Problem.from_fixture(fx), solver))
+                    except Exception as e:  # a panic of the reference's setup: must be raised on both sides
+                        out.append(("raised", type(e).__name__))
+                a, b = out
+                if isinstance(a, tuple) or isinstance(b, tuple):
+                    assert a == b, (k, solver, a if isinstance(a, tuple) else "ok", b if isinstance(b, tuple) else "ok")
+                    continue
+                assert (a is None) == (b is None), (k, solver)
+                if a is None:
+                    continue
+                n_cmp += 1
+                for key in a:
+                    if isinstance(a[key], np.ndarray):
+                        np.testing.assert_array_equal(a[key], b[key], err_msg=f"case {k} {solver}: {key}")
+                    else:
+                        assert a[key] == b[key], (k, solver, key)
+    finally:
+        if old is None:
+            os.environ.pop("ELLP_QR_DEVICE", None)
+        else:
+            os.environ["ELLP_QR_DEVICE"] = old
+    assert n_cmp > 250
