@@ -2855,6 +2855,15 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
     if (phase == 0) {
         int64_t period = e->refactor_period > 0 ? e->refactor_period : default_period(e);
         if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
+        // the follow-up of a serviced maintenance request (see ellp_engine_run): B^-1 is refreshed once
+        // more after the single iteration that follows the request.  maint_chain: 1 = that iteration
+        // starts now, 2 = it has run
+        if (e->maint_chain == 2) {
+            maintain_inverse(e);
+            e->maint_chain = 0;
+        } else if (e->maint_chain == 1) {
+            e->maint_chain = 2;
+        }
         if (e->kind == ELLP_ENGINE_PRIMAL) {
             const bool full_btran =
                 (e->opts.btran_mode == 1) || !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;

@@ -149,6 +149,7 @@ class ShardedEngine:
         done = 0
         with self.torch.cuda.stream(self.stream):
             status, stats, msg = self.eng.poll()
+            it0 = stats.iters
             while status == E.MAXITER and done < max_iters:
                 batch = min(poll_interval, max_iters - done)
                 # one host call + one collective per iteration: step(2) = rest of iteration k and
@@ -158,8 +159,10 @@ class ShardedEngine:
                 for k in range(batch):
                     self.exchange()
                     self.eng.step(2 if k + 1 < batch else 1)
-                done += batch
                 status, stats, msg = self.eng.poll()
+                # iterations that really ran: a maintenance request voids the rest of its batch (the
+                # device state is replicated, so every rank computes the same count)
+                done = stats.iters - it0
         return status, stats, msg
 
     def read_point(self):
