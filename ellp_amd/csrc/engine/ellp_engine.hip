@@ -87,6 +87,7 @@ struct DevState {
     double d_r, alpha_r;
     // ---- results
     double lambda, obj;
+    double drift;  // last k_drift_reduce: max|A_B (B^-1 a_q) - a_q| / max|a_q|
     unsigned long long iters, pivots, flips;
 #ifdef ELLP_DBG_STAMPS
     long long dbg[3][4][8];  // [kernel][block selector][stamp] wall_clock64 (100 MHz) — dev builds only
@@ -1523,6 +1524,77 @@ __global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
     a.u[j] = s;
 }
 
+// ------------------------------------------------------------------ drift monitor of B^-1
+// The reference factorises A_B afresh every iteration; here B^-1 carries the rounding of every eta
+// update since its last refresh, and how fast that grows depends on the LP (a tall 500 x 100 LP of
+// the benign synthetic family reached 1e-9 in x after 160 updates, config 3 stays at 1e-12 after
+// 1000).  So every few iterations the FTRAN result is checked against the basis itself:
+// t = A_B * alpha - a_q must vanish (alpha = B^-1 a_q = +-d).  One GEMV over A_B (8*m*ld bytes),
+// same shape as k_btran_part: tiles of basis columns, coalesced along the rows, partials in
+// `upart`; k_drift_reduce folds them in a fixed order (deterministic: replicated engines of a
+// sharded run must take the same decision) and raises DevState::tiny — the maintenance request of
+// a tiny pivot — when max|t| exceeds drift_tol * max|a_q|.
+struct DriftArgs {
+    const double *A_B, *A_N, *d;
+    double *upart;
+    DevState *st;
+    int64_t m, ld;
+    int cols_per_tile, ntiles;
+    double tol;
+};
+__global__ __launch_bounds__(256) void k_drift_part(DriftArgs a) {
+    if (a.st->status != ST_RUNNING) return;
+    const int64_t half = a.ld >> 1;
+    const int64_t i2 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.y * a.cols_per_tile;
+    const int64_t k1 = (k0 + a.cols_per_tile < a.m) ? k0 + a.cols_per_tile : a.m;
+    if (i2 >= half) return;
+    const double2 *AB2 = reinterpret_cast<const double2 *>(a.A_B);
+    double2 acc = make_double2(0.0, 0.0);
+    for (int64_t k = k0; k < k1; ++k) {
+        const double dk = a.d[k];
+        const double2 c = AB2[k * half + i2];
+        acc.x = fma(dk, c.x, acc.x);
+        acc.y = fma(dk, c.y, acc.y);
+    }
+    reinterpret_cast<double2 *>(a.upart)[(int64_t)blockIdx.y * half + i2] = acc;
+}
+__global__ __launch_bounds__(1024) void k_drift_reduce(DriftArgs a) {
+    __shared__ double s_r[16], s_s[16];
+    DevState *st = a.st;
+    if (st->status != ST_RUNNING) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double sgn = st->s_at_lower ? -1.0 : 1.0;  // alpha = sgn * d (k_ftran2 stores d = +-alpha)
+    const double *aq = a.A_N + st->s_q * a.ld;
+    double res = 0.0, scale = 0.0;
+    for (int64_t i = tid; i < a.m; i += 1024) {
+        double t = 0.0;
+        for (int k = 0; k < a.ntiles; ++k) t += a.upart[(int64_t)k * a.ld + i];
+        const double q = aq[i];
+        res = fmax(res, fabs(sgn * t - q));
+        scale = fmax(scale, fabs(q));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        res = fmax(res, __shfl_xor(res, o));
+        scale = fmax(scale, __shfl_xor(scale, o));
+    }
+    if (lane == 0) {
+        s_r[wave] = res;
+        s_s[wave] = scale;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) {
+            res = fmax(res, s_r[w]);
+            scale = fmax(scale, s_s[w]);
+        }
+        const double rel = res / (scale > 0.0 ? scale : 1.0);
+        st->drift = rel;
+        if (rel > a.tol || rel != rel) st->tiny = 1;
+    }
+}
+
 // ------------------------------------------------------------------ refactorisation of B^-1 from A_B
 // Product-form rebuild with partial pivoting: start from W = I and bring the m basic columns
 // in one at a time: alpha = W a_k, pivot row p = first max |alpha_i| over the rows not used yet
@@ -1892,6 +1964,9 @@ struct ellp_engine {
     bool need_dleave = true;
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
+    int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
+    double drift_tol = 0.0;
+    uint64_t since_drift = 0, drift_checks = 0;
     // launch geometry
     int cpb = 1, nblocks = 1, priceT = 1;
     bool price_nt = false;
@@ -2151,13 +2226,24 @@ double launch_refresh(ellp_engine *e) {
     return res;
 }
 
-// Default maintenance period: a refresh costs ~2*(2 m^3)/25 TFLOP/s + one host sync, an iteration
-// ~(8 ld |N| + 24 m ld)/5 TB/s + 15 us; clamp(m/2, 64, 1000) keeps the overhead at a few percent
-// at every size while small (often degenerate) LPs, whose refresh is nearly free, stay close to
-// the reference's always-fresh factorisation.
+// Default maintenance period, from a cost model: a refresh costs T_r ~ 2*(2 m^3)/25 TFLOP/s + 60 us
+// (two GEMM launches, a residual read-back with a host sync), an iteration T_i ~ (8 ld |N| + 24 m ld)
+// / 5 TB/s + 15 us, and the period is the smallest one whose refreshes stay within a BUDGET of the
+// loop time: 30 % up to m = 1024, falling linearly to 3 % at m = 2000 and beyond (config 3: 1000
+// iterations, as measured), never below 16.  Why so generous on small and mid-size LPs: the reference
+// factorises afresh every iteration, and the error of B^-1 a_q is cond(A_B) times that of B^-1 — a
+// tall 500 x 100 LP of the benign synthetic family left the oracle's path after 166 pivots with B^-1
+// untouched and after 162 with a period of 62 (x off by 2e-9 against EPS = 1e-10; the error grew
+// 25-fold within 9 pivots at cond 6e4), and stays on it for 1200 pivots with a period of 16.  Beyond
+// the model, the drift monitor (k_drift_part) asks for a refresh when the LP needs one.
 int64_t default_period(const ellp_engine *e) {
-    int64_t p = e->m / 2;
-    if (p < 64) p = 64;
+    const double m = (double)e->m, ld = (double)e->ld, nN = (double)(e->nN > 0 ? e->nN : 1);
+    const double t_refresh = 4.0 * m * m * m / 25e12 + 60e-6;
+    const double t_iter = (8.0 * ld * nN + 24.0 * m * ld) / 5e12 + 15e-6;
+    double budget = 0.30;
+    if (m > 1024.0) budget = m >= 2000.0 ? 0.03 : 0.30 - 0.27 * (m - 1024.0) / 976.0;
+    int64_t p = (int64_t)std::ceil(t_refresh / (budget * t_iter));
+    if (p < 16) p = 16;
     if (p > 1000) p = 1000;
     return p;
 }
@@ -2186,6 +2272,19 @@ bool service_maintenance_request(ellp_engine *e) {
     return true;
 }
 
+// between k_ftran2 and k_update2 of an iteration: see k_drift_part
+void launch_drift_check(ellp_engine *e) {
+    if (e->drift_every <= 0) return;
+    if (++e->since_drift < (uint64_t)e->drift_every) return;
+    e->since_drift = 0;
+    e->drift_checks += 1;
+    DriftArgs a{e->A_B, e->A_N, e->d, e->upart, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles, e->drift_tol};
+    const int64_t half = e->ld >> 1;
+    hipLaunchKernelGGL(k_drift_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0,
+                       e->stream, a);
+    hipLaunchKernelGGL(k_drift_reduce, dim3(1), dim3(1024), 0, e->stream, a);
+}
+
 void launch_primal_iteration(ellp_engine *e) {
     const bool full_btran = (e->opts.btran_mode == 1) || !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;
     if (full_btran) {
@@ -2202,6 +2301,7 @@ void launch_primal_iteration(ellp_engine *e) {
         Prof p(e, ELLP_K_FTRAN);
         launch_ftran2<0>(e);
     }
+    launch_drift_check(e);
     {
         Prof p(e, ELLP_K_UPDATE);
         launch_update2<0>(e, e->opts.btran_mode == 1 ? 0 : 1);
@@ -2219,6 +2319,7 @@ void launch_dual_iteration(ellp_engine *e) {
         Prof p(e, ELLP_K_FTRAN);
         launch_ftran2<1>(e);
     }
+    launch_drift_check(e);
     {
         Prof p(e, ELLP_K_DUPDATE);
         launch_update2<1>(e, 0);
@@ -2449,6 +2550,15 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         e->ftran_lds = sizeof(double) * (size_t)e->nblocks + 16;
         e->refactor_period = e->opts.refactor_period > 0 ? e->opts.refactor_period : 0;
         e->ill_tol = (m <= 512) ? 1e-3 : 0.0;
+        // drift monitor: only where refreshes are rare (period > 64), four checks per period; one GEMV
+        // over A_B + a one-block fold, ~70 us at config 3 (0.7 % of the loop)
+        {
+            const int64_t p = e->refactor_period > 0 ? e->refactor_period : default_period(e);
+            e->drift_every = p > 64 ? (int)(p / 4 > 64 ? p / 4 : 64) : 0;
+        }
+        e->drift_tol = 1e-10;  // a backstop: config 3 drifts to 1.4e-11 in 3000 updates without any refresh
+        if (const char *v = getenv("ELLP_DRIFT_EVERY"); v && v[0]) e->drift_every = atoi(v);  // diagnostics
+        if (const char *v = getenv("ELLP_DRIFT_TOL"); v && v[0]) e->drift_tol = atof(v);        // diagnostics
     }
 
     ECHK(dmalloc(e, &e->A_B, (size_t)(ld * m)));
@@ -2627,52 +2737,56 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             remaining = 0;
         }
         const uint64_t iters0 = e->h_st->iters;
-        // Look-ahead polling (no reactive maintenance, no profiling): batch k+1 is enqueued BEFORE
-        // the host waits for the status of batch k, so the stream never drains while the host
-        // looks at a read-back.  A batch enqueued after termination is a few no-op launches
-        // (every kernel returns at once when status != RUNNING).  Each launched iteration is
-        // exactly one device iteration while the status is RUNNING, so the host's count is exact.
-        const bool lookahead = e->ill_tol <= 0.0 && !e->opts.profile && remaining > 0;
-        if (lookahead) {
-            if (!e->h_look) {
-                HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_look), 2 * sizeof(DevState), hipHostMallocDefault));
-                HIPCHK(hipEventCreateWithFlags(&e->look_ev[0], hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&e->look_ev[1], hipEventDisableTiming));
-            }
-            const uint64_t lpoll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 64;
-            bool pending[2] = {false, false};
-            bool terminal = false;
-            int slot = 0;
-            while (!terminal) {
-                if (remaining > 0) {
-                    const uint64_t batch = remaining < lpoll ? remaining : lpoll;
-                    for (uint64_t it = 0; it < batch; ++it) {
-                        if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
-                        if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
-                        else launch_dual_iteration(e);
+        const bool can_look_ahead = e->ill_tol <= 0.0 && !e->opts.profile;
+        while (remaining > 0 && result == ELLP_MAXITER) {
+            // Look-ahead polling (no tiny-pivot maintenance, no profiling, no follow-up refresh due):
+            // batch k+1 is enqueued BEFORE the host waits for the status of batch k, so the stream never
+            // drains while the host looks at a read-back.  A batch enqueued after termination — or after a
+            // maintenance request of the drift monitor — is a few no-op launches (every kernel returns at
+            // once when status != RUNNING).  Iterations are counted on the device afterwards.
+            if (can_look_ahead && e->maint_chain == 0) {
+                if (!e->h_look) {
+                    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_look), 2 * sizeof(DevState), hipHostMallocDefault));
+                    HIPCHK(hipEventCreateWithFlags(&e->look_ev[0], hipEventDisableTiming));
+                    HIPCHK(hipEventCreateWithFlags(&e->look_ev[1], hipEventDisableTiming));
+                }
+                const uint64_t lpoll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 64;
+                bool pending[2] = {false, false};
+                bool stop = false;
+                int slot = 0;
+                uint64_t to_launch = remaining;
+                while (!stop) {
+                    if (to_launch > 0) {
+                        const uint64_t batch = to_launch < lpoll ? to_launch : lpoll;
+                        for (uint64_t it = 0; it < batch; ++it) {
+                            if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
+                            if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
+                            else launch_dual_iteration(e);
+                        }
+                        to_launch -= batch;
+                        HIPCHK(hipMemcpyAsync(&e->h_look[slot], e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+                        HIPCHK(hipEventRecord(e->look_ev[slot], e->stream));
+                        pending[slot] = true;
                     }
-                    remaining -= batch;
-                    HIPCHK(hipMemcpyAsync(&e->h_look[slot], e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
-                    HIPCHK(hipEventRecord(e->look_ev[slot], e->stream));
-                    pending[slot] = true;
+                    const int other = slot ^ 1;
+                    const int wait_on = pending[other] ? other : (to_launch == 0 && pending[slot] ? slot : -1);
+                    if (wait_on >= 0) {
+                        HIPCHK(hipEventSynchronize(e->look_ev[wait_on]));
+                        pending[wait_on] = false;
+                        if (e->h_look[wait_on].status != ST_RUNNING || e->h_look[wait_on].tiny) stop = true;
+                    }
+                    if (to_launch == 0 && !pending[0] && !pending[1]) break;
+                    slot ^= 1;
                 }
-                const int other = slot ^ 1;
-                const int wait_on = pending[other] ? other : (remaining == 0 && pending[slot] ? slot : -1);
-                if (wait_on >= 0) {
-                    HIPCHK(hipEventSynchronize(e->look_ev[wait_on]));
-                    pending[wait_on] = false;
-                    if (e->h_look[wait_on].status != ST_RUNNING) terminal = true;
-                }
-                if (remaining == 0 && !pending[0] && !pending[1]) break;
-                slot ^= 1;
+                HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+                HIPCHK(hipStreamSynchronize(e->stream));
+                HIPCHK(hipGetLastError());
+                const uint64_t done = e->h_st->iters - iters0;
+                remaining = done < max_iters ? max_iters - done : 0;
+                if (service_maintenance_request(e)) continue;  // refreshed; the follow-up runs in the loop below
+                if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
+                continue;
             }
-            HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(hipStreamSynchronize(e->stream));
-            HIPCHK(hipGetLastError());
-            if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
-            remaining = 0;
-        }
-        while (remaining > 0) {
             const bool chained = e->maint_chain > 0;
             const uint64_t batch = chained ? 1 : (remaining < poll ? remaining : poll);
             for (uint64_t it = 0; it < batch; ++it) {
@@ -2690,10 +2804,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             if (chained) e->maint_chain = 0;
             if (service_maintenance_request(e)) continue;
             if (chained && e->h_st->status == ST_RUNNING) maintain_inverse(e);  // the follow-up refresh
-            if (e->h_st->status != ST_RUNNING) {
-                result = status_message(*e->h_st, errbuf, errlen);
-                break;
-            }
+            if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
         }
     }
     if (stats) {
@@ -2761,6 +2872,11 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
         const double v[12] = {(double)h.status, (double)h.cur, (double)h.s_q, (double)h.s_r, h.s_theta_d, h.s_delta,
                               (double)h.lr, h.ldelta, (double)h.iters, (double)h.pivots, h.lambda, h.s_rq};
         for (int k = 0; k < 12; ++k) dst[k] = v[k];
+        if (cap >= 14) {  // + last drift estimate of B^-1 (k_drift_reduce) and the number of checks so far
+            dst[12] = h.drift;
+            dst[13] = (double)e->drift_checks;
+            return 14;
+        }
         return 12;
     }
     case ELLP_TAP_BINV: {
@@ -2889,6 +3005,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
                 Prof p(e, ELLP_K_FTRAN);
                 launch_ftran2<0>(e);
             }
+            launch_drift_check(e);
             Prof p(e, ELLP_K_UPDATE);
             launch_update2<0>(e, e->opts.btran_mode == 1 ? 0 : 1);
             e->since_btran += 1;
@@ -2897,6 +3014,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
                 Prof p(e, ELLP_K_FTRAN);
                 launch_ftran2<1>(e);
             }
+            launch_drift_check(e);
             Prof p(e, ELLP_K_DUPDATE);
             launch_update2<1>(e, 0);
         }

@@ -269,3 +269,30 @@ def test_primal_large_reduced_costs(scale):
     assert st_o2 == st_g2 == eo.OPTIMAL and it_o2 > 50 and stats2.iters > 50
     assert abs(fp2.obj() - ov2.obj()) <= 1e-9 * abs(ov2.obj())
     np.testing.assert_allclose(fp2.x, ov2.x, rtol=0, atol=1e-9 * (1 + np.abs(ov2.x).max()))
+
+
+@pytest.mark.parametrize("m,n,W", [(500, 100, 600), (400, 900, 1200)])
+def test_primal_tall_and_square_synthetic_window(m, n, W):
+    """More rows than structural columns: the end of phase 1 runs through bases of condition 1e4-1e5,
+    where the error of B^-1 a_q (cond(A_B) times that of B^-1) decides whether x stays within EPS of
+    the oracle's.  With B^-1 untouched the engine left the oracle's path at pivot 166 of the 500 x 100
+    LP; with the default maintenance (a refresh every 16 iterations at this size) it stays on it."""
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(5, m, n)
+
+    class V:
+        pass
+    ov = V()
+    for k, val in f.items():
+        setattr(ov, k, val.copy() if hasattr(val, "copy") else val)
+    ov.nB, ov.nN = len(f["B"]), len(f["N"])
+    st_o, it_o, _ = eo.primal_solve_with_initial(ov, W)
+    E = _engine()
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    st_g, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o and stats.iters == it_o, msg
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_array_equal(fp.Nb, ov.Nb)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-10)
