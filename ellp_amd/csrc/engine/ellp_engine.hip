@@ -75,6 +75,7 @@ struct DevState {
     // ---- snapshot written by k_ftran2 block 0, read by k_update2 (which never writes it)
     int32_t s_cur, s_at_lower, s_side, s_pad;
     int64_t s_q, s_jq, s_r;
+    int64_t s_lv;  // dual: the leaving variable B_index[s_r] as k_ftran2 saw it
     double s_rq, s_lambda0, s_delta, s_theta_d;
     // ---- dual: leaving row for the coming iteration (written by k_dleave / k_update2<1> block 0)
     int64_t lr;
@@ -908,6 +909,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         } else {
             st->s_jq = a.N_index[q];
             st->s_r = st->lr;
+            st->s_lv = a.B_index[st->lr];
             st->s_delta = st->ldelta;
             st->s_side = st->lside;
             st->s_theta_d = theta_d;
@@ -1140,9 +1142,10 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     int64_t r;
     double lambda = 0.0;
     int side = 0;
-    // the first NBK blocks do bookkeeping only (primal 1; dual 2: block 0 the O(|N|) reduced-cost
-    // update, block 1 the rest); blocks NBK.. stream rows_per_block (<= 4) rows each
-    constexpr int NBK = MODE == 0 ? 1 : 2;
+    // the first NBK blocks do bookkeeping only (primal 1; dual 3: block 0 the O(|N|) reduced-cost
+    // update, block 1 y / the column swap / the nonbasic side, block 2 x / the basic side / the next
+    // leaving row); blocks NBK.. stream rows_per_block rows each
+    constexpr int NBK = MODE == 0 ? 1 : 3;
     const bool row_block = blockIdx.x >= NBK;
     const int64_t row0 = ((int64_t)blockIdx.x - NBK) * a.rows_per_block;
     double dv[UPD_ROWS];
@@ -1406,7 +1409,6 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     } else {
         // dual…:296-316
         const double theta_d = st->s_theta_d, delta = st->s_delta;
-        const int64_t leaving_var = a.B_index[r];
         const double theta_p = delta / d_r;
         const double *rho = src + r * a.ld;
         if (blockIdx.x == 0) {  // block 0: d[N_j] -= theta_d * alpha_j for every nonbasic j != q
@@ -1428,25 +1430,33 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         }
         return;
         }
-        // block 1: y, x, the swap, the scalars and the next leaving row
+        if (blockIdx.x == 1) {
+            // block 1: y, the column swap and everything indexed by the nonbasic position q.  The leaving
+            // variable comes from the snapshot: block 2 overwrites B_index[r] meanwhile.
+            const int64_t lv = st->s_lv;
+            for (int64_t i = tid; i < m; i += 256) a.y[i] = a.y[i] + theta_d * rho[i];
+            swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
+            if (tid == 0) {
+                a.dd[lv] = -theta_d;
+                a.dd[jq] = 0.0;
+                a.N_index[q] = lv;  // dual…:322-333
+                a.Nb[q] = (uint8_t)st->s_side;
+                const double tc = a.c_N[q];
+                a.c_N[q] = a.c_B[r];
+                a.c_B[r] = tc;
+            }
+            return;
+        }
+        // block 2: x, the basic side of the swap, the scalars and the next leaving row
         for (int64_t i = tid; i < m; i += 256) {
-            a.y[i] = a.y[i] + theta_d * rho[i];
             const int64_t bi = a.B_index[i];
             a.x[bi] = a.x[bi] - theta_p * a.d[i];
         }
         __syncthreads();
-        swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
         if (tid == 0) {
-            a.dd[leaving_var] = -theta_d;
-            a.dd[jq] = 0.0;
             a.x[jq] = a.x[jq] + theta_p;
             st->obj = st->obj + theta_d * delta;
-            a.B_index[r] = jq;  // dual…:322-333
-            a.N_index[q] = leaving_var;
-            a.Nb[q] = (uint8_t)st->s_side;
-            const double tc = a.c_N[q];
-            a.c_N[q] = a.c_B[r];
-            a.c_B[r] = tc;
+            a.B_index[r] = jq;
             st->cur = cur ^ 1;
             st->pivots += 1;
             st->iters += 1;
@@ -2164,7 +2174,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd2_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
-    const dim3 g(e->upd2_blocks + (MODE == 0 ? 1 : 2)), b(256);
+    const dim3 g(e->upd2_blocks + (MODE == 0 ? 1 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
     if (nr <= 1) hipLaunchKernelGGL((k_update2<MODE, 1>), g, b, lds, e->stream, a);
