@@ -1142,10 +1142,11 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     int64_t r;
     double lambda = 0.0;
     int side = 0;
-    // the first NBK blocks do bookkeeping only (primal 1; dual 3: block 0 the O(|N|) reduced-cost
+    // the first NBK blocks do bookkeeping only (primal 2: block 0 x / the basic side / the counters,
+    // block 1 u / the column swap / the nonbasic side; dual 3: block 0 the O(|N|) reduced-cost
     // update, block 1 y / the column swap / the nonbasic side, block 2 x / the basic side / the next
     // leaving row); blocks NBK.. stream rows_per_block rows each
-    constexpr int NBK = MODE == 0 ? 1 : 3;
+    constexpr int NBK = MODE == 0 ? 2 : 3;
     const bool row_block = blockIdx.x >= NBK;
     const int64_t row0 = ((int64_t)blockIdx.x - NBK) * a.rows_per_block;
     double dv[UPD_ROWS];
@@ -1345,6 +1346,34 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         tiny_pivot = fabs(d_r) < a.ill_tol * amax;
     }
     if (MODE == 0) {
+        if (blockIdx.x == 1) {
+            // block 1: u += (r_q / alpha_r) * rho, the column swap and everything indexed by the nonbasic
+            // position q.  The leaving variable comes from bidx[] (B_index as k_ftran2 saw it): block 0
+            // overwrites B_index[r] meanwhile.
+            if (r < 0) return;  // bound flip: block 0 does it
+            if (a.update_u) {
+                const double cf = st->s_rq / alpha_r;
+                const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
+                double2 *u2 = reinterpret_cast<double2 *>(a.u);
+                for (int64_t t = tid; t < (a.ld >> 1); t += 256) {
+                    const double2 p = rho2[t];
+                    double2 w = u2[t];
+                    w.x = fma(cf, p.x, w.x);
+                    w.y = fma(cf, p.y, w.y);
+                    u2[t] = w;
+                }
+            }
+            swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
+            if (tid == 0) {
+                const double tc = a.c_N[q];
+                a.c_N[q] = a.c_B[r];
+                a.c_B[r] = tc;
+                a.N_index[q] = a.bidx[r];
+                a.Nb[q] = (uint8_t)side;
+            }
+            return;
+        }
+        // block 0: the point, the basic side of the swap, the counters
         if (lambda > 0.0) {  // primal…:408-417
             for (int64_t i0 = tid; i0 < m; i0 += 4 * 256) {
                 int64_t bi[4];
@@ -1366,28 +1395,10 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 else a.x[jq] = a.x[jq] - lambda;
             }
         }
-        __syncthreads();  // B_index reads above vs the swap below
+        __syncthreads();  // B_index reads above vs the write below
         if (r >= 0) {
-            if (a.update_u) {
-                const double cf = st->s_rq / alpha_r;
-                const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
-                double2 *u2 = reinterpret_cast<double2 *>(a.u);
-                for (int64_t t = tid; t < (a.ld >> 1); t += 256) {
-                    const double2 p = rho2[t];
-                    double2 w = u2[t];
-                    w.x = fma(cf, p.x, w.x);
-                    w.y = fma(cf, p.y, w.y);
-                    u2[t] = w;
-                }
-            }
-            swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
             if (tid == 0) {
-                const double tc = a.c_N[q];
-                a.c_N[q] = a.c_B[r];
-                a.c_B[r] = tc;
-                a.N_index[q] = a.B_index[r];
                 a.B_index[r] = jq;
-                a.Nb[q] = (uint8_t)side;
                 st->lambda = lambda;
                 st->cur = cur ^ 1;
                 st->pivots += 1;
@@ -2174,7 +2185,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd2_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
-    const dim3 g(e->upd2_blocks + (MODE == 0 ? 1 : 3)), b(256);
+    const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
     if (nr <= 1) hipLaunchKernelGGL((k_update2<MODE, 1>), g, b, lds, e->stream, a);
