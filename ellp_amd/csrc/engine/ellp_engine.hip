@@ -1191,23 +1191,25 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             }
             if (!rows_issued) {
                 rows_issued = true;
-        // The rows this block rewrites do not depend on which row pivots: issue them into
-            // registers now (behind the small staging loads) so the HBM stream overlaps the fold.
-            __builtin_amdgcn_sched_barrier(0);
-            if (NR > 0) {  // every block, block 0 included (clamped): same loads in flight on all paths
+                // The rows this block rewrites do not depend on which row pivots: issue them into
+                // registers now (behind the small staging loads) so the HBM stream overlaps the fold.
+                // (Tried and not better: all rows only after the staging data has arrived, half of them
+                // before and half after, non-temporal row loads.)
+                __builtin_amdgcn_sched_barrier(0);
+                if (NR > 0) {  // every block, bookkeeping blocks included (clamped): same loads in flight on all paths
 #pragma unroll
-                for (int k = 0; k < UPD_ROWS; ++k) {
-                    const int64_t i = row0 + k;
-                    const bool ok = row_block && k < a.rows_per_block && i < m;
-                    const double2 *srow = reinterpret_cast<const double2 *>(src + (ok ? i : 0) * a.ld);
+                    for (int k = 0; k < UPD_ROWS; ++k) {
+                        const int64_t i = row0 + k;
+                        const bool ok = row_block && k < a.rows_per_block && i < m;
+                        const double2 *srow = reinterpret_cast<const double2 *>(src + (ok ? i : 0) * a.ld);
 #pragma unroll
-                    for (int u = 0; u < NR; ++u) {
-                        const int64_t t = tid + 256 * u;
-                        const double2 wv = srow[t < halfw ? t : 0];
-                        wreg[k][u] = (ok && t < halfw) ? wv : make_double2(0.0, 0.0);
+                        for (int u = 0; u < NR; ++u) {
+                            const int64_t t = tid + 256 * u;
+                            const double2 wv = srow[t < halfw ? t : 0];
+                            wreg[k][u] = (ok && t < halfw) ? wv : make_double2(0.0, 0.0);
+                        }
                     }
                 }
-            }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
