@@ -1618,6 +1618,94 @@ __global__ __launch_bounds__(1024) void k_drift_reduce(DriftArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ resynchronising x_B with the basis
+// The reference updates x incrementally (x_B += lambda d, primal…:408-417; x_B -= theta_p alpha_q,
+// dual…:308-313) from a d / alpha_q of LU quality at every iteration.  Here d comes from a B^-1
+// that is only as good as its last refresh, and what a few ill-conditioned bases add to x stays
+// there: a netlib ADLITTLE in another variable order ended its dual phase 1 "Infeasible" because a
+// basic variable sat at -8e-10 — 2.6e-9 away from B^-1 (b - N x_N) on a basis of condition 1e3 —
+// and was picked as leaving row with no eligible column.  So whenever B^-1 has just been refreshed,
+// x_B is recomputed from it:  t = b - A_N x_N  (k_resync_part over A_N + k_resync_rhs),
+// cand_i = B^-1[i,:] . t  (k_resync_xb) — and adopted only if it differs from the carried x_B by more
+// than 1e-11 (1 + max|x_B|) somewhere (k_resync_apply): on benign LPs the carried x is as good as
+// the reference's and keeps the reference's rounding path (a tall synthetic LP whose phase 1 ends on
+// EPS-ties stays pivot-for-pivot), on LPs that went through ill-conditioned bases the error is
+// removed before it can flip an EPS decision.  The nonbasic values are left exactly as they are.
+struct ResyncArgs {
+    const double *A_N, *W0, *W1, *b;
+    double *x, *xg, *tvec, *upart, *cand;
+    unsigned long long *maxbits;  // [0] max|cand - x_B|, [1] max|x_B| as bit patterns (non-negative doubles)
+    const int64_t *B_index, *N_index;
+    DevState *st;
+    int64_t m, ld, nN;
+    int cols_per_tile, ntiles;
+};
+__global__ __launch_bounds__(256) void k_resync_gather(ResyncArgs a) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < a.nN) a.xg[j] = a.x[a.N_index[j]];
+}
+// partial[tile][i] = sum over the tile's columns j of A_N[i,j] * xg[j]   (coalesced along i)
+__global__ __launch_bounds__(256) void k_resync_part(ResyncArgs a) {
+    if (a.st->status != ST_RUNNING && a.st->status != ST_NEED_MAINT) return;
+    const int64_t half = a.ld >> 1;
+    const int64_t i2 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.y * a.cols_per_tile;
+    const int64_t j1 = (j0 + a.cols_per_tile < a.nN) ? j0 + a.cols_per_tile : a.nN;
+    if (i2 >= half) return;
+    const double2 *AN2 = reinterpret_cast<const double2 *>(a.A_N);
+    double2 acc = make_double2(0.0, 0.0);
+    for (int64_t j = j0; j < j1; ++j) {
+        const double xj = a.xg[j];
+        if (xj == 0.0) continue;
+        const double2 c = AN2[j * half + i2];
+        acc.x = fma(xj, c.x, acc.x);
+        acc.y = fma(xj, c.y, acc.y);
+    }
+    reinterpret_cast<double2 *>(a.upart)[(int64_t)blockIdx.y * half + i2] = acc;
+}
+__global__ __launch_bounds__(256) void k_resync_rhs(ResyncArgs a) {
+    if (a.st->status != ST_RUNNING && a.st->status != ST_NEED_MAINT) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.ld) return;
+    double s = 0.0;
+    for (int k = 0; k < a.ntiles; ++k) s += a.upart[(int64_t)k * a.ld + i];
+    a.tvec[i] = i < a.m ? a.b[i] - s : 0.0;
+}
+// one wave per basic row: cand_i = B^-1[i,:] . t, and the two maxima the decision needs (a maximum is
+// exact in any order: atomicMax on the bit pattern of a non-negative double)
+__global__ __launch_bounds__(256) void k_resync_xb(ResyncArgs a) {
+    if (a.st->status != ST_RUNNING && a.st->status != ST_NEED_MAINT) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.m) return;
+    const int64_t half = a.ld >> 1;
+    const double2 *row = reinterpret_cast<const double2 *>((a.st->cur ? a.W1 : a.W0) + i * a.ld);
+    const double2 *t2 = reinterpret_cast<const double2 *>(a.tvec);
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int64_t t = lane; t < half; t += WAVE) {
+        const double2 w = row[t], v = t2[t];
+        acc0 = fma(w.x, v.x, acc0);
+        acc1 = fma(w.y, v.y, acc1);
+    }
+    const double r = wave_sum(acc0 + acc1);
+    if (lane == 0) {
+        const double xo = a.x[a.B_index[i]];
+        a.cand[i] = r;
+        const double df = fabs(r - xo), ax = fabs(xo);
+        if (df == df) atomicMax(&a.maxbits[0], (unsigned long long)__double_as_longlong(df));
+        else atomicMax(&a.maxbits[0], 0x7ff0000000000000ull);  // NaN: adopt nothing sensible anyway
+        if (ax == ax) atomicMax(&a.maxbits[1], (unsigned long long)__double_as_longlong(ax));
+    }
+}
+__global__ __launch_bounds__(256) void k_resync_apply(ResyncArgs a) {
+    if (a.st->status != ST_RUNNING && a.st->status != ST_NEED_MAINT) return;
+    const double maxdiff = __longlong_as_double((long long)a.maxbits[0]);
+    const double maxx = __longlong_as_double((long long)a.maxbits[1]);
+    if (!(maxdiff > 1e-11 * (1.0 + maxx)) || isinf(maxdiff)) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.m) a.x[a.B_index[i]] = a.cand[i];
+}
+
 // ------------------------------------------------------------------ refactorisation of B^-1 from A_B
 // Product-form rebuild with partial pivoting: start from W = I and bring the m basic columns
 // in one at a time: alpha = W a_k, pivot row p = first max |alpha_i| over the rows not used yet
@@ -1968,6 +2056,9 @@ struct ellp_engine {
     hipStream_t stream = nullptr;
     // device memory
     double *A_B = nullptr, *A_N = nullptr, *W = nullptr, *W2 = nullptr;
+    double *b_dev = nullptr, *xg = nullptr, *tvec = nullptr, *cand = nullptr;  // resync of x_B (k_resync_*)
+    unsigned long long *maxbits = nullptr;
+    uint64_t resyncs = 0;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
@@ -2272,9 +2363,44 @@ int64_t default_period(const ellp_engine *e) {
 }
 
 // periodic maintenance of B^-1: Newton-Schulz refresh, full rebuild only if that is not safe
-void maintain_inverse(ellp_engine *e) {
+void launch_dleave(ellp_engine *e);
+
+// x_B from the freshly maintained B^-1 (see k_resync_part)
+void launch_resync(ellp_engine *e) {
+    if (e->nN <= 0) return;
+    ResyncArgs a{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
+                 e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles};
+    (void)hipMemsetAsync(e->maxbits, 0, 2 * sizeof(unsigned long long), e->stream);
+    a.cols_per_tile = (int)((e->nN + e->btran_tiles - 1) / e->btran_tiles);
+    const int64_t half = e->ld >> 1;
+    hipLaunchKernelGGL(k_resync_gather, dim3((unsigned)((e->nN + 255) / 256)), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_resync_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0,
+                       e->stream, a);
+    hipLaunchKernelGGL(k_resync_rhs, dim3((unsigned)((e->ld + 255) / 256)), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_resync_xb, dim3((unsigned)((e->m + 3) / 4)), dim3(256), 0, e->stream, a);
+    hipLaunchKernelGGL(k_resync_apply, dim3((unsigned)((e->m + 255) / 256)), dim3(256), 0, e->stream, a);
+    if (e->kind == ELLP_ENGINE_DUAL) launch_dleave(e);  // the leaving row is chosen from x (dual…:200-236)
+    e->resyncs += 1;
+    if (getenv("ELLP_RESYNC_DEBUG")) {  // diagnostics: what the resync found
+        unsigned long long hb[2] = {0, 0};
+        (void)hipMemcpyAsync(hb, e->maxbits, sizeof(hb), hipMemcpyDeviceToHost, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        double dv[2];
+        memcpy(dv, hb, sizeof(dv));
+        fprintf(stderr, "ellp resync %llu: max|cand - x_B| %.3e, max|x_B| %.3e\n", (unsigned long long)e->resyncs, dv[0], dv[1]);
+    }
+}
+
+// Maintenance of B^-1: Newton-Schulz refresh, full rebuild if that is not safe, then x_B is checked
+// against the fresh inverse (launch_resync).  `reactive` (asked for by the device, or the follow-up of
+// such a request) is kept for diagnostics: resynchronising only then was tried and is worse (netlib
+// ADLITTLE / BLEND in 60 variable orders, dual: 4 wrong outcomes instead of 1).
+void maintain_inverse(ellp_engine *e, bool reactive = false) {
     const double res = launch_refresh(e);
     if (!(res >= 0.0 && res < 1e-4)) launch_refactor(e);
+    const char *mode = getenv("ELLP_RESYNC");  // diagnostics: "0" never, "1" only on reactive maintenance
+    const bool want = mode && mode[0] == '0' ? false : (mode && mode[0] == '1' ? reactive : true);
+    if (want) launch_resync(e);
 }
 
 // After a status read-back: if a kernel asked for maintenance, do it, re-arm the loop and report
@@ -2283,7 +2409,7 @@ bool service_maintenance_request(ellp_engine *e) {
     // the request is the status (a later pricing launch of the batch saw the flag) or still the flag
     // (the batch ended with the k_update2 that raised it)
     if (e->h_st->status != ST_NEED_MAINT && !(e->h_st->status == ST_RUNNING && e->h_st->tiny)) return false;
-    maintain_inverse(e);
+    maintain_inverse(e, true);
     e->maint_chain = 1;
     const int32_t running = ST_RUNNING, zero = 0;
     (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
@@ -2599,6 +2725,12 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->ub, (size_t)n_c));
     ECHK(dmalloc(e, &e->kindv, (size_t)n_c));
     ECHK(dmalloc(e, &e->d, (size_t)ld));
+    ECHK(dmalloc(e, &e->b_dev, (size_t)ld));
+    ECHK(dmalloc(e, &e->tvec, (size_t)ld));
+    ECHK(dmalloc(e, &e->cand, (size_t)ld));
+    ECHK(dmalloc(e, &e->maxbits, (size_t)2));
+    ECHK(dmalloc(e, &e->xg, (size_t)nNa));
+    ECHK(hipMemsetAsync(e->b_dev, 0, sizeof(double) * (size_t)ld, e->stream));
     ECHK(dmalloc(e, &e->upart, (size_t)(e->btran_tiles * ld)));
     ECHK(dmalloc(e, &e->B_index, (size_t)m));
     ECHK(dmalloc(e, &e->N_index, (size_t)nNa));
@@ -2648,6 +2780,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
             UCHK(hipMemcpyAsync(e->Nb, N_bound, (size_t)n_N, hipMemcpyHostToDevice, e->stream));
         }
         UCHK(hipMemcpyAsync(e->x, x, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(e->b_dev, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, e->stream));
         UCHK(hipMemcpyAsync(e->lb, lb, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
         UCHK(hipMemcpyAsync(e->ub, ub, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
         UCHK(hipMemcpyAsync(e->kindv, bound_kind, (size_t)n_c, hipMemcpyHostToDevice, e->stream));
@@ -2826,7 +2959,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             remaining = done < max_iters ? max_iters - done : 0;
             if (chained) e->maint_chain = 0;
             if (service_maintenance_request(e)) continue;
-            if (chained && e->h_st->status == ST_RUNNING) maintain_inverse(e);  // the follow-up refresh
+            if (chained && e->h_st->status == ST_RUNNING) maintain_inverse(e, true);  // the follow-up refresh
             if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
         }
     }
@@ -2998,7 +3131,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
         // more after the single iteration that follows the request.  maint_chain: 1 = that iteration
         // starts now, 2 = it has run
         if (e->maint_chain == 2) {
-            maintain_inverse(e);
+            maintain_inverse(e, true);
             e->maint_chain = 0;
         } else if (e->maint_chain == 1) {
             e->maint_chain = 2;

@@ -87,7 +87,9 @@ def _worker(rank, world, port, q):
                 same_status=(st == st_ref), status=int(st), iters=int(stats.iters), iters_ref=int(stats_ref.iters),
                 expect=(int(st_ref) if cap < 100000 else E.OPTIMAL),
                 same_B=bool(np.array_equal(fp.B, ref_fp.B)), same_N=bool(np.array_equal(fp.N, ref_fp.N)),
-                same_x=bool(np.array_equal(fp.x, ref_fp.x)), msg=msg)
+                # same pivots; x to rounding: the two drivers may refresh B^-1 (and with it x_B) at different
+                # moments, e.g. inside a batch that a maintenance request has voided
+                same_x=bool(np.allclose(fp.x, ref_fp.x, rtol=0, atol=1e-10 * (1 + np.abs(ref_fp.x).max()))), msg=msg)
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -169,7 +171,7 @@ def test_library_loop_with_direct_rccl_world1():
         assert stats.iters == stats_ref.iters
         np.testing.assert_array_equal(fp.B, ref_fp.B)
         np.testing.assert_array_equal(fp.N, ref_fp.N)
-        np.testing.assert_array_equal(fp.x, ref_fp.x)
+        np.testing.assert_allclose(fp.x, ref_fp.x, rtol=0, atol=1e-10 * (1 + np.abs(ref_fp.x).max()))
 
 
 def test_run_sharded_needs_a_communicator():

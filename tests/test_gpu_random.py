@@ -260,3 +260,56 @@ def test_random_wide_lps_first_400_pivots():
     assert n["primal"] >= 14
     primal = [b for b in bad if b[0][1].startswith("primal") and not (b[1] == "status" and "lambda >= 0" in str(b[4]) + str(b[5]))]
     assert not primal, primal[:5]
+
+
+def _permuted(fx, rng):
+    """The same LP with its variables and constraints in another order (the reference builds its
+    problems by iterating HashMaps, tests/problems/mod.rs:657-674, so every order occurs)."""
+    n = len(fx["vars"])
+    perm = rng.permutation(n)            # new index k holds old variable perm[k]
+    inv = np.empty(n, dtype=int)
+    inv[perm] = np.arange(n)
+    rows = [fx["constraints"][i] for i in rng.permutation(len(fx["constraints"]))]
+    return {"vars": [fx["vars"][j] for j in perm],
+            "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
+
+
+@pytest.mark.parametrize("name", ["afiro", "adlittle", "blend"])
+def test_netlib_in_random_orders(name):
+    """Real, sparse, degenerate LPs in 6 random variable/constraint orders each: primal phase by phase
+    pivot for pivot against the oracle, and the pinned optimum (tests/problems/mod.rs:658-672) at the
+    end, for the primal loop and for the dual loop (objective only: exact-minimum ties)."""
+    import os
+    from helpers import GOLDEN, known_answers, read_mps
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == name)
+    base = read_mps(os.path.join(GOLDEN, ka["file"]))
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    n_paths = 0
+    for trial in range(6):
+        fx = _permuted(base, rng)
+        prob = eo.Problem.from_fixture(fx)
+        # primal, at the seam
+        p1, err = eo.primal_phase1(prob)
+        bad = []
+        r = seam(p1.view(), "primal", 5000)
+        compare((trial, "primal1"), *r, bad)
+        assert r[1] == r[4] == eo.OPTIMAL and abs(r[0].obj()) < 1e-10 and abs(r[3].obj()) < 1e-9
+        p1.store_point(r[0])
+        r2 = seam(eo.primal_phase2(p1).view(), "primal", 5000)
+        compare((trial, "primal2"), *r2, bad)
+        assert r2[1] == r2[4] == eo.OPTIMAL and abs(r2[3].obj() / ka["obj"] - 1.0) < 1e-6
+        # pivot for pivot except where a degenerate tie falls the other way (same objective then)
+        assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
+        n_paths += len(bad)
+        # dual, at the seam: same status and objective
+        d1, err = eo.dual_phase1(prob)
+        rd = seam(d1.view(), "dual", 20000)
+        assert rd[1] == rd[4] == eo.OPTIMAL, (trial, rd[1], rd[4], rd[7])
+        d1.store_point(rd[0])
+        d2, err2 = eo.dual_phase2(d1)
+        assert d2 is not None and not err2
+        rd2 = seam(d2.view(), "dual", 20000)
+        assert rd2[1] == rd2[4] == eo.OPTIMAL, (trial, rd2[1], rd2[4], rd2[7])
+        assert abs(rd2[3].obj() / ka["obj"] - 1.0) < 1e-6 and abs(rd2[0].obj() / ka["obj"] - 1.0) < 1e-6
+    assert n_paths <= 3, n_paths  # of 12 primal phase runs
