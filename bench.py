@@ -136,6 +136,31 @@ def main():
     assert st == E.MAXITER and steps_done == args.steps, (E.STATUS_NAME.get(st), steps_done, msg)
     refactors = stats.refactors
     resid = eng.inverse_residual() if world == 1 else None
+    sharded_check = None
+    if world > 1:
+        # outside the timed region: the sharded run must have taken the pivots of a single-GPU run
+        # (rank 0 replays them unsharded) and every rank must hold the same basis
+        import zlib
+        eng.read_point()
+        crc = zlib.crc32(fp.B.tobytes() + fp.N.tobytes() + fp.Nb.tobytes())
+        tcrc = torch.tensor([crc], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        allcrc = [torch.zeros_like(tcrc) for _ in range(world)]
+        dist.all_gather(allcrc, tcrc)
+        ranks_agree = all(int(t.item()) == crc for t in allcrc)
+        same_as_single = None
+        if rank == 0:
+            fp1 = E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
+                                flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"], flat.get("y"),
+                                flat.get("d"))
+            ref = E.Engine(kind, fp1, E.default_opts(max_iter=None, device=local_rank,
+                                                    refactor_period=args.refactor_period, btran_mode=args.btran_mode))
+            ref.run(args.warmup)
+            ref.run(args.steps)
+            ref.read_point()
+            ref.close()
+            same_as_single = bool(np.array_equal(fp1.B, fp.B) and np.array_equal(fp1.N, fp.N) and
+                                  np.array_equal(fp1.Nb, fp.Nb))
+        sharded_check = {"all_ranks_hold_the_same_basis": bool(ranks_agree), "same_pivots_as_one_gpu": same_as_single}
     eng.close()
 
     # ---- per-kernel durations (HIP events on the engine's stream), same start, separate run
@@ -245,7 +270,8 @@ def main():
                                 f"std-form {m}x{fp.n} with |N|={nN}"), "refactors_in_window": int(refactors),
                    "inverse_residual_after": resid,
                    "parallelism": ("single GPU" if world == 1 else
-                                   f"column-block pricing sharded over {world} GPUs, 1 all-gather/iteration")},
+                                   f"column-block pricing sharded over {world} GPUs, 1 all-gather/iteration"),
+                   "sharded_check": sharded_check},
         "achieved_GBps_algorithmic": round(alg_bytes_per_pivot * args.steps / dt / 1e9, 1),
         "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v["avg_us"], 3) for k, v in prof.items()},
     }
