@@ -235,7 +235,7 @@ def main():
                "sample": f"first {iters} pivots of the same LP from the same starting basis, {cdt:.1f} s, "
                          "oracle/ellp_oracle.c (LU refactor every iteration, single thread)"}
     cpu_same = None
-    if cpu_pivots > 0 and not dual:
+    if cpu_pivots > 0:
         # the ENGINE's algorithm (explicit B^-1, eta updates, same pivot rules)
         # on all host cores, so the GPU/CPU ratio is not only the reference's LU-per-iteration cost
         from oracle import ellp_oracle as eo
@@ -250,13 +250,14 @@ def main():
             v.nB, v.nN = len(flat["B"]), len(flat["N"])
             return v
         cores = eo.host_threads()
-        _, it_p, _, secs_p = eo.primal_binv_solve_with_initial(fresh(), 40, threads=cores)  # probe the rate
+        same_loop = eo.dual_binv_solve_with_initial if dual else eo.primal_binv_solve_with_initial
+        _, it_p, _, secs_p = same_loop(fresh(), 40, threads=cores)  # probe the rate
         k_same = int(max(40, min(args.same_alg_pivots, 8.0 * it_p / max(secs_p, 1e-9))))   # <= ~8 s
-        st_c, it_c, msg_c, secs_c = eo.primal_binv_solve_with_initial(fresh(), k_same, threads=cores)
+        st_c, it_c, msg_c, secs_c = same_loop(fresh(), k_same, threads=cores)
         if it_c > 0 and secs_c > 0:
             cpu_same = {"value": round(it_c / secs_c, 2), "unit": "pivots/s", "cores": cores, "kind": "port",
                         "sample": f"first {it_c} pivots of the same LP from the same starting basis, {secs_c:.1f} s, "
-                                  "oracle/ellp_oracle.c eo_primal_binv_solve_with_initial (explicit B^-1 + eta "
+                                  "oracle/ellp_oracle.c eo_%s_binv_solve_with_initial (explicit B^-1 + eta " % ("dual" if dual else "primal") +
                                   "updates like the engine, OpenMP over the host cores)"}
     alg_bytes_per_pivot = 8.0 * ld * nN + (24.0 if dual else 32.0) * m * ld
     out = {

@@ -1684,6 +1684,221 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
     return status;
 }
 
+/* ------------------------------------------------------------------ dual loop, explicit B^-1
+ * As eo_primal_binv_solve_with_initial: the reference's dual pivot rules (dual…:200-333) with B^-1
+ * kept explicitly (eta updates, what the HIP engine does) and the big passes on OpenMP threads.
+ * Checked against eo_dual_solve_with_initial in tests/test_oracle_binv.py; used for long dual
+ * windows at full size. */
+int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,
+                                    const double *c, const double *b, const uint8_t *kind,
+                                    const double *lb, const double *ub, double *x, int64_t *B,
+                                    int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y,
+                                    double *d, uint64_t max_iter, uint64_t *iters_out, int threads,
+                                    int refresh, double *loop_seconds, char *err, size_t errlen) {
+    (void)c;
+    (void)b;
+    (void)n_c;
+    if (iters_out) *iters_out = 0;
+    if (loop_seconds) *loop_seconds = 0.0;
+    if (m <= 0 || nB != m || n < m || nN != n - m) {
+        set_err(err, errlen, "bad dimensions");
+        return EO_ERR_BAD_DIMS;
+    }
+    for (int64_t j = 0; j < nN; ++j) { /* :139-151 */
+        double di = d[N[j]];
+        int infeasible;
+        if (Nb[j] == EO_NB_LOWER) infeasible = di < -EPS;
+        else if (Nb[j] == EO_NB_UPPER) infeasible = di > EPS;
+        else infeasible = fabs(di) > EPS;
+        if (infeasible) {
+            set_err(err, errlen, "initial point of dual phase 2 is dual infeasible");
+            return EO_ERR_PANIC;
+        }
+    }
+    if (nN == 0) return EO_OPTIMAL;
+    if (threads < 1) threads = 1;
+    double *A_B = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *A_N = (double *)xmalloc(sizeof(double) * (size_t)(m * nN));
+    for (int64_t i = 0; i < m; ++i) memcpy(A_B + i * m, A + B[i] * m, sizeof(double) * (size_t)m);
+    for (int64_t j = 0; j < nN; ++j) memcpy(A_N + j * m, A + N[j] * m, sizeof(double) * (size_t)m);
+    double *W = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *rho = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *alpha = (double *)xmalloc(sizeof(double) * (size_t)nN);
+    double *alpha_q = (double *)xmalloc(sizeof(double) * (size_t)m);
+    int status = EO_ERR_PANIC;
+    uint64_t iter = 0, entered = 0, since_refresh = 0;
+    double t0 = 0.0;
+    /* the dual loop has no singularity guard (dual…:241-253 unwrap): only an exactly singular basis fails */
+    {
+        lu_t f;
+        lu_factor(&f, A_B, m, m);
+        int bad = 0;
+#pragma omp parallel num_threads(threads)
+        {
+            double *e = (double *)xmalloc(sizeof(double) * (size_t)m);
+#pragma omp for schedule(static)
+            for (int64_t k = 0; k < m; ++k) {
+                memset(e, 0, sizeof(double) * (size_t)m);
+                e[k] = 1.0;
+                if (!lu_solve(&f, e)) {
+#pragma omp atomic write
+                    bad = 1;
+                }
+                for (int64_t i = 0; i < m; ++i) W[i * m + k] = e[i];
+            }
+            free(e);
+        }
+        lu_free(&f);
+        if (bad) {
+            set_err(err, errlen, "unwrap() on None: singular basis");
+            goto done;
+        }
+    }
+    t0 = now_seconds();
+    for (;;) {
+        if (iter >= max_iter) {
+            status = EO_MAXITER;
+            break;
+        }
+        iter += 1;
+        entered += 1;
+        if (refresh > 0 && since_refresh >= (uint64_t)refresh) {
+            lu_t f;
+            lu_factor(&f, A_B, m, m);
+            double *e = (double *)xmalloc(sizeof(double) * (size_t)m);
+            int bad = 0;
+            for (int64_t k = 0; k < m && !bad; ++k) {
+                memset(e, 0, sizeof(double) * (size_t)m);
+                e[k] = 1.0;
+                if (!lu_solve(&f, e)) bad = 1;
+                for (int64_t i = 0; i < m; ++i) W[i * m + k] = e[i];
+            }
+            free(e);
+            lu_free(&f);
+            if (bad) {
+                set_err(err, errlen, "unwrap() on None: singular basis");
+                break;
+            }
+            since_refresh = 0;
+        }
+        int64_t r = -1;
+        double delta = 0.0;
+        int side = EO_NB_LOWER;
+        for (int64_t i = 0; i < m && r < 0; ++i) { /* :200-236 */
+            const int64_t bi = B[i];
+            double xi = x[bi];
+            switch (kind[bi]) {
+            case EO_LOWER:
+                if (xi < lb[bi] - EPS) { r = i; delta = xi - lb[bi]; side = EO_NB_LOWER; }
+                break;
+            case EO_UPPER:
+                if (xi > ub[bi] + EPS) { r = i; delta = xi - ub[bi]; side = EO_NB_UPPER; }
+                break;
+            case EO_TWOSIDED:
+                if (xi > ub[bi] + EPS) { r = i; delta = xi - ub[bi]; side = EO_NB_UPPER; }
+                else if (xi < lb[bi] - EPS) { r = i; delta = xi - lb[bi]; side = EO_NB_LOWER; }
+                break;
+            default: break;
+            }
+        }
+        if (r < 0) {
+            status = EO_OPTIMAL;
+            break;
+        }
+        memcpy(rho, W + r * m, sizeof(double) * (size_t)m);
+#pragma omp parallel for schedule(static) num_threads(threads)
+        for (int64_t j = 0; j < nN; ++j) {
+            const double dot = dot4(A_N + j * m, rho, m);
+            alpha[j] = (delta < 0.0) ? -dot : dot;
+        }
+        int64_t q = -1;
+        double theta_dual = 0.0;
+        int nan_seen = 0;
+        for (int64_t j = 0; j < nN; ++j) { /* :263-279 */
+            int keep;
+            if (Nb[j] == EO_NB_LOWER) keep = alpha[j] > EPS;
+            else if (Nb[j] == EO_NB_UPPER) keep = alpha[j] < -EPS;
+            else keep = 1;
+            if (!keep) continue;
+            double ratio = d[N[j]] / alpha[j];
+            if (q < 0) {
+                q = j;
+                theta_dual = ratio;
+            } else {
+                if (isnan(ratio) || isnan(theta_dual)) {
+                    nan_seen = 1;
+                    break;
+                }
+                if (theta_dual > ratio) {
+                    q = j;
+                    theta_dual = ratio;
+                }
+            }
+        }
+        if (nan_seen) {
+            set_err(err, errlen, "unwrap() on None: NaN in dual ratio test");
+            status = EO_ERR_NAN;
+            break;
+        }
+        if (q < 0) {
+            status = EO_INFEASIBLE;
+            break;
+        }
+        if (delta < 0.0) {
+            for (int64_t j = 0; j < nN; ++j) alpha[j] = -alpha[j];
+            theta_dual = -theta_dual;
+        }
+        const int64_t leaving_var = B[r];
+        const int64_t entering_var = N[q];
+        {
+            const double *aq = A_N + q * m;
+#pragma omp parallel for schedule(static) num_threads(threads)
+            for (int64_t i = 0; i < m; ++i) alpha_q[i] = dot4(W + i * m, aq, m);
+        }
+        if (alpha_q[r] == 0.0) {
+            set_err(err, errlen, "unwrap() on None in dual FTRAN");
+            break;
+        }
+        d[leaving_var] = -theta_dual;
+        for (int64_t j = 0; j < nN; ++j) d[N[j]] -= theta_dual * alpha[j];
+        d[entering_var] = 0.0;
+        for (int64_t i = 0; i < m; ++i) y[i] += theta_dual * rho[i];
+        double theta_primal = delta / alpha_q[r];
+        for (int64_t i = 0; i < m; ++i) x[B[i]] -= theta_primal * alpha_q[i];
+        x[entering_var] += theta_primal;
+        if (g_trace) g_trace(g_trace_user, entered, q, r, entering_var, leaving_var);
+        { /* B^-1 <- E B^-1 */
+            const double ar = alpha_q[r];
+#pragma omp parallel for schedule(static) num_threads(threads)
+            for (int64_t i = 0; i < m; ++i) {
+                double *wi = W + i * m;
+                if (i == r) {
+                    for (int64_t k = 0; k < m; ++k) wi[k] = rho[k] / ar;
+                } else {
+                    const double f = -(alpha_q[i] / ar);
+                    if (f != 0.0)
+                        for (int64_t k = 0; k < m; ++k) wi[k] = f * rho[k] + wi[k];
+                }
+            }
+        }
+        B[r] = entering_var;
+        N[q] = leaving_var;
+        Nb[q] = (uint8_t)side;
+        double *cb = A_B + r * m, *cn = A_N + q * m;
+        for (int64_t i = 0; i < m; ++i) {
+            double t = cb[i];
+            cb[i] = cn[i];
+            cn[i] = t;
+        }
+        since_refresh += 1;
+    }
+    if (loop_seconds) *loop_seconds = now_seconds() - t0;
+done:
+    if (iters_out) *iters_out = entered;
+    free(A_B); free(A_N); free(W); free(rho); free(alpha); free(alpha_q);
+    return status;
+}
+
 /* ------------------------------------------------------------------ DualPhase1 / DualPhase2 */
 
 static eo_problem *problem_clone(const eo_problem *p) {

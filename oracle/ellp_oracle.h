@@ -138,6 +138,14 @@ int eo_primal_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const d
                                       uint64_t max_iter, uint64_t *iters, int threads, int refresh,
                                       double *loop_seconds, char *err, size_t errlen);
 
+/* The dual counterpart (dual…:200-333 with an explicit B^-1). */
+int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A,
+                                    const double *c, const double *b, const uint8_t *kind,
+                                    const double *lb, const double *ub, double *x, int64_t *B,
+                                    int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y,
+                                    double *d, uint64_t max_iter, uint64_t *iters, int threads,
+                                    int refresh, double *loop_seconds, char *err, size_t errlen);
+
 /* Optional per-iteration trace for pivot-sequence parity (entering position, leaving
  * position or -1, objective). Set to NULL to disable.  Not thread-safe (test use only). */
 typedef void (*eo_trace_fn)(void *user, uint64_t iter, int64_t entering_pos,

@@ -99,6 +99,9 @@ def lib():
     L.eo_primal_solve_with_initial.argtypes = common + tail
     L.eo_dual_solve_with_initial.restype = C.c_int
     L.eo_dual_solve_with_initial.argtypes = common + [C.c_void_p, C.c_void_p] + tail
+    L.eo_dual_binv_solve_with_initial.restype = C.c_int
+    L.eo_dual_binv_solve_with_initial.argtypes = common + [C.c_void_p, C.c_void_p] + [
+        C.c_uint64, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
     L.eo_primal_binv_solve_with_initial.restype = C.c_int
     L.eo_primal_binv_solve_with_initial.argtypes = common + [
         C.c_uint64, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
@@ -311,6 +314,21 @@ def primal_binv_solve_with_initial(ph, max_iter=MAX_ITER_NONE, threads=None, ref
         ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
         _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
         max_iter, C.byref(it), int(threads), int(refresh), C.byref(secs), err, 256)
+    return st, it.value, err.value.decode(), secs.value
+
+
+def dual_binv_solve_with_initial(ph, max_iter=MAX_ITER_NONE, threads=None, refresh=0):
+    """The dual loop with the same pivoting rules and an explicitly maintained B^-1 on OpenMP threads.
+    Returns (status, iters, err, loop_seconds)."""
+    if threads is None:
+        threads = host_threads()
+    it = C.c_uint64(0)
+    secs = C.c_double(0.0)
+    err = C.create_string_buffer(256)
+    st = lib().eo_dual_binv_solve_with_initial(
+        ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
+        _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
+        _ptr(ph.y), _ptr(ph.d), max_iter, C.byref(it), int(threads), int(refresh), C.byref(secs), err, 256)
     return st, it.value, err.value.decode(), secs.value
 
 

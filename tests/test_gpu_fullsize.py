@@ -90,6 +90,27 @@ def test_c4_dual_window_parity(dual_flat):
     np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-9 * (1 + np.abs(ov.d).max()))
 
 
+def test_c4_dual_long_window_parity(dual_flat):
+    """3000 dual pivots (500 on a slow host) at full size against the explicit-B^-1 CPU dual loop (same
+    rules as the oracle's, checked against it in tests/test_oracle_binv.py)."""
+    from ellp_amd import _engine as E
+    f = dual_flat
+    _, it_p, _, secs_p = eo.dual_binv_solve_with_initial(_view(f), 40)
+    W = 3000 if it_p / max(secs_p, 1e-9) > 100.0 else 500
+    ov = _view(f)
+    st_o, it_o, msg_o, _ = eo.dual_binv_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"], f["y"], f["d"])
+    st_g, stats, msg = E.dual_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, (msg, msg_o)
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_array_equal(fp.Nb, ov.Nb)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
+    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-8 * (1 + np.abs(ov.d).max()))
+    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-8 * (1 + np.abs(ov.y).max()))
+
+
 def test_c3_primal_invariants_over_a_long_run(primal_flat):
     """3000 iterations in slices: A x = b, objective non-increasing, bounds, W A_B = I."""
     from ellp_amd import _engine as E
