@@ -204,3 +204,25 @@ def test_big_m_dual_window_parity():
     assert st_g == E.MAXITER, msg
     assert eng.inverse_residual() < 1e-10
     eng.close()
+
+
+def test_c5_primal_window_parity():
+    """Config 5 itself (m=4000, n=40000: 1.4 GB of nonbasic columns streamed with non-temporal loads from
+    2048 pricing blocks, 8-row update blocks, streamed FTRAN rows): the first 400 pivots (150 on a slow
+    host) equal those of the explicit-B^-1 CPU loop."""
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(20260305, 4000, 40000)
+    _, it_p, _, secs_p = eo.primal_binv_solve_with_initial(_view(f), 10)
+    W = 400 if it_p / max(secs_p, 1e-9) > 30.0 else 150
+    ov = _view(f)
+    st_o, it_o, msg_o, _ = eo.primal_binv_solve_with_initial(ov, W)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    del f
+    st_g, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, (msg, msg_o)
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N)
+    np.testing.assert_array_equal(fp.Nb, ov.Nb)
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
