@@ -183,3 +183,41 @@ def test_standard_form_identical_on_random_lps():
         else:
             os.environ["ELLP_QR_DEVICE"] = old
     assert n_cmp > 250
+
+
+@pytest.mark.parametrize("m,n", [(150, 400), (60, 5000), (300, 40)])
+def test_standard_form_identical_on_mid_size_dense_lps(m, n):
+    """Shapes that exercise the multi-block paths of the QR kernels: more than 256 columns of A^T,
+    several row chunks in the update, a pivot column longer than one LDS chunk (n + m > 4096), and a
+    tall A.  The phase-1 arrays must be identical whichever side ran the QR."""
+    from ellp_amd import Bound, ConstraintOp, Problem, synth
+    A, b, c = synth.dense_lp(20260301, m, n)
+    A[m // 2] = A[1] + 0.5 * A[2]          # a redundant row: the rank decision matters
+    b[m // 2] = b[1] + 0.5 * b[2]
+
+    def build():
+        p = Problem()
+        ids = [p.add_var(float(c[j]), Bound.Lower(0.0)) for j in range(n)]
+        for i in range(m):
+            op = ConstraintOp.Eq if i in (1, 2, m // 2) else ConstraintOp.Lte
+            p.add_constraint(list(zip(ids, A[i].tolist())), op, float(b[i]))
+        return p
+    old = os.environ.get("ELLP_QR_DEVICE")
+    try:
+        os.environ["ELLP_QR_DEVICE"] = "0"
+        a = _phase1_arrays(build(), "primal")
+        os.environ["ELLP_QR_DEVICE"] = "1"
+        d = _phase1_arrays(build(), "primal")
+    finally:
+        if old is None:
+            os.environ.pop("ELLP_QR_DEVICE", None)
+        else:
+            os.environ["ELLP_QR_DEVICE"] = old
+    assert (a is None) == (d is None)
+    if a is not None:
+        assert a["m"] == d["m"] == m - 1            # the redundant row is gone on both sides
+        for key in a:
+            if isinstance(a[key], np.ndarray):
+                np.testing.assert_array_equal(a[key], d[key], err_msg=key)
+            else:
+                assert a[key] == d[key], key
