@@ -7,10 +7,23 @@ A "step" is one iteration of the revised-simplex loop (one pass of the hot path:
 BTRAN/pricing/entering/FTRAN/ratio/eta-update) on the synthetic dense LP of BASELINE.json's
 config 3 (m=2000, n=5000, primal; SURVEY.md §8d generator), started from the reference's own
 phase-1 starting basis, tableau already resident in HBM.  Prints ONE JSON line (rank 0).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N … bench.py …`) BEFORE it touches
+torch or HIP, relays their output and exits with their return code.  Under torchrun (WORLD_SIZE
+set) it is one of the ranks.  N ranks cooperate on ONE pivot stream: the nonbasic columns (storage
+and pricing) are sharded, everything else is replicated ("scaling": "strong").
+
+Besides the headline workload (config 3, so that N=1 is comparable from round to round) every line
+carries a `config5` object: BASELINE.json's config 5 (m=4000, n=40000, primal), the one it names
+for 1/2/4/8 GPUs, run the same way — pivots/s, the pricing kernel's rate per GPU and its fraction
+of the HBM roofline.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -18,9 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured-achievable)
+EVENT_NOTE = ("HIP-event brackets on the engine's stream minus the bracket calibration `event_cost` "
+              "(tools/event_cal.hip: an event pair reads that much more than rocprofv3's duration of the "
+              "kernel inside it); raw brackets = these + event_cost; the rocprofv3 --kernel-trace --stats "
+              "averages of the same command are committed under profiles/")
 
 
 def parse():
@@ -39,8 +54,41 @@ def parse():
     ap.add_argument("--refactor-period", type=int, default=0)
     ap.add_argument("--btran-mode", type=int, default=0)
     ap.add_argument("--poll", type=int, default=0)
-    ap.add_argument("--check", action="store_true", help="compare the first pivots with the oracle")
+    ap.add_argument("--pipeline", type=int, default=-1, help="-1 engine default, 0 three kernels per iteration, 1 two")
+    ap.add_argument("--config5", type=int, default=-1,
+                    help="1/0: also run config 5 (m=4000 n=40000) and report it as `config5` (-1: yes when the "
+                         "headline workload is config 3)")
+    ap.add_argument("--config5-steps", type=int, default=1000)
+    ap.add_argument("--long-window", type=int, default=3000,
+                    help="when --steps < 1000: additionally time a window of this many steps (0 off)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without torchrun: start the N ranks as a child job.  Nothing here touches HIP
+    (torch.cuda.device_count() only counts, it does not initialise a device)."""
+    n = args.gpus
+    backend = os.environ.get("ELLP_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception as e:  # pragma: no cover
+            print(f"bench.py: cannot count HIP devices: {e}", file=sys.stderr)
+            return 2
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} HIP devices, this node has {have} "
+                  "(ELLP_BENCH_BACKEND=gloo ELLP_BENCH_DEVICE=0 runs the ranks on one device as a dry run)",
+                  file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(flat, pivots, solver="primal"):
@@ -71,156 +119,260 @@ def cpu_baseline(flat, pivots, solver="primal"):
     return iters / dt, iters, dt, v
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
-    # test hooks (dry runs on a 1-GPU box): ELLP_BENCH_BACKEND=gloo, ELLP_BENCH_DEVICE=0
-    backend = os.environ.get("ELLP_BENCH_BACKEND", "nccl")
-    if "ELLP_BENCH_DEVICE" in os.environ:
-        local_rank = int(os.environ["ELLP_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+class Ctx:
+    """process-group context of this rank"""
 
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # test hooks (dry runs on a 1-GPU box): ELLP_BENCH_BACKEND=gloo, ELLP_BENCH_DEVICE=0
+        self.backend = os.environ.get("ELLP_BENCH_BACKEND", "nccl")
+        if "ELLP_BENCH_DEVICE" in os.environ:
+            self.local_rank = int(os.environ["ELLP_BENCH_DEVICE"])
+        self.dist = None
+
+    def init(self):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, v):
+        if self.dist is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_equal(self, value):
+        if self.dist is None:
+            return True
+        t = self.torch.tensor([value], dtype=self.torch.int64, device="cuda" if self.backend == "nccl" else "cpu")
+        parts = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return all(int(p.item()) == value for p in parts)
+
+
+def pmc_traffic(m, n, solver, dual):
+    """HBM traffic of the pricing kernel per launch, from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction; tools/pmc_traffic.sh).  It is
+    read from profiles/, not measured in this run: the file it came from is named beside it."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            pm = json.load(open(f))
+        except Exception:
+            continue
+        if pm.get("workload") != f"m={m} n={n} {solver}":
+            continue
+        mode = "1" if dual else "0"
+        for kname, kv in pm["kernels"].items():
+            hit = False
+            for prefix in ("k_price_wave<", "k_price2_wave<"):
+                if kname.startswith(prefix):
+                    hit = kname[len(prefix):].rstrip(">").strip() == mode
+            for prefix in ("k_price<", "k_price2<"):
+                if kname.startswith(prefix):
+                    hit = kname.split(",")[1].strip().rstrip(">") == mode
+            if hit:
+                return kv["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
+
+
+def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_window=0):
+    """One workload on this process group: W warm-up steps, K timed steps bracketed by barrier +
+    synchronize on both sides (max over ranks), an optional longer window, per-kernel event times from
+    a second run, and — sharded — the self-check against a single-GPU replay."""
+    import numpy as np
     from ellp_amd import _engine as E
     from ellp_amd import synth
+    torch = ctx.torch
+    world, rank = ctx.world, ctx.rank
+    dual = solver == "dual"
+    flat = synth.dual_start_flat(seed, m, n) if dual else synth.primal_phase1_flat(seed, m, n)
 
-    m, n = args.m, args.n
-    dual = args.solver == "dual"
-    flat = synth.dual_start_flat(args.seed, m, n) if dual else synth.primal_phase1_flat(args.seed, m, n)
-    fp = E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
-                       flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"],
-                       flat.get("y"), flat.get("d"))
+    def make_fp():
+        return E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
+                             flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"], flat.get("y"),
+                             flat.get("d"))
+    fp = make_fp()
     kind = E.ENGINE_DUAL if dual else E.ENGINE_PRIMAL
     nN = fp.nN
     ld = (m + 15) // 16 * 16
 
-    def make_engine(profile):
-        opts = E.default_opts(max_iter=None, device=local_rank, refactor_period=args.refactor_period,
-                              btran_mode=args.btran_mode, poll_interval=args.poll, profile=profile)
+    def opts_for(profile, pipeline=None):
+        kw = dict(max_iter=None, device=ctx.local_rank, refactor_period=args.refactor_period,
+                  btran_mode=args.btran_mode, poll_interval=args.poll, profile=profile)
+        if hasattr(E.Opts, "pipeline"):  # ellp_opts.pipeline: 0 engine default, 1 three launches, 2 two
+            kw["pipeline"] = (args.pipeline if pipeline is None else pipeline) + 1
+        return E.default_opts(**kw)
+
+    def make_engine(profile, f=None):
         if world > 1:
-            # column-block pricing sharded over the ranks, one RCCL all-gather per iteration
             from ellp_amd.dist import ShardedEngine
-            return ShardedEngine(kind, fp, opts)
-        return E.Engine(kind, fp, opts)
+            return ShardedEngine(kind, f or fp, opts_for(profile))
+        return E.Engine(kind, f or fp, opts_for(profile))
 
     # ---- timed region: tableau resident, W warm-up steps, then exactly K steps
     eng = make_engine(0)
-    st, stats, msg = eng.run(args.warmup)
+    st, stats, msg = eng.run(warmup)
     assert st in (E.MAXITER,), f"warm-up ended the solve: {E.STATUS_NAME.get(st)} {msg}"
     it0 = stats.iters
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    ctx.barrier()
     t0 = time.perf_counter()
-    st, stats, msg = eng.run(args.steps)
+    st, stats, msg = eng.run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        dist.barrier()
-        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ctx.barrier()
+    dt = ctx.max_over_ranks(dt)
     steps_done = stats.iters - it0
-    assert st == E.MAXITER and steps_done == args.steps, (E.STATUS_NAME.get(st), steps_done, msg)
-    refactors = stats.refactors
-    resid = eng.inverse_residual() if world == 1 else None
-    sharded_check = None
+    assert st == E.MAXITER and steps_done == steps, (E.STATUS_NAME.get(st), steps_done, msg)
+    out = {"dt": dt, "steps": steps, "refactors": int(stats.refactors), "ld": ld, "nN": nN, "n_cols": fp.n,
+           "flat": flat}
+    total_after = warmup + steps
+    if long_window > 0:
+        it1 = stats.iters
+        ctx.barrier()
+        t0 = time.perf_counter()
+        st, stats, msg = eng.run(long_window)
+        torch.cuda.synchronize()
+        ldt = time.perf_counter() - t0
+        ctx.barrier()
+        ldt = ctx.max_over_ranks(ldt)
+        assert st == E.MAXITER and stats.iters - it1 == long_window, (E.STATUS_NAME.get(st), msg)
+        out["long_window"] = {"steps": long_window, "value": round(long_window / ldt, 2), "unit": "pivots/s",
+                              "ms_per_step": round(1e3 * ldt / long_window, 6)}
+        total_after += long_window
+    out["resid"] = eng.inverse_residual() if world == 1 else None
     if world > 1:
         # outside the timed region: the sharded run must have taken the pivots of a single-GPU run
         # (rank 0 replays them unsharded) and every rank must hold the same basis
         import zlib
         eng.read_point()
         crc = zlib.crc32(fp.B.tobytes() + fp.N.tobytes() + fp.Nb.tobytes())
-        tcrc = torch.tensor([crc], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
-        allcrc = [torch.zeros_like(tcrc) for _ in range(world)]
-        dist.all_gather(allcrc, tcrc)
-        ranks_agree = all(int(t.item()) == crc for t in allcrc)
+        ranks_agree = ctx.all_equal(crc)
         same_as_single = None
         if rank == 0:
-            fp1 = E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
-                                flat["lb"], flat["ub"], flat["x"], flat["B"], flat["N"], flat["Nb"], flat.get("y"),
-                                flat.get("d"))
-            ref = E.Engine(kind, fp1, E.default_opts(max_iter=None, device=local_rank,
-                                                    refactor_period=args.refactor_period, btran_mode=args.btran_mode))
-            ref.run(args.warmup)
-            ref.run(args.steps)
+            fp1 = make_fp()
+            ref = E.Engine(kind, fp1, opts_for(0))
+            ref.run(total_after)
             ref.read_point()
             ref.close()
             same_as_single = bool(np.array_equal(fp1.B, fp.B) and np.array_equal(fp1.N, fp.N) and
                                   np.array_equal(fp1.Nb, fp.Nb))
-        sharded_check = {"all_ranks_hold_the_same_basis": bool(ranks_agree), "same_pivots_as_one_gpu": same_as_single}
+        out["sharded_check"] = {"all_ranks_hold_the_same_basis": bool(ranks_agree),
+                                "same_pivots_as_one_gpu": same_as_single,
+                                "exchange": getattr(eng, "exchange_name", None)}
+        ok = ranks_agree and (same_as_single is None or same_as_single)
+        if not ctx.all_equal(1 if ok else 0) or not ok:
+            if rank == 0:
+                print(json.dumps({"error": "sharded run diverged from the single-GPU pivots", "workload": f"m={m} n={n}",
+                                  "sharded_check": out["sharded_check"]}), file=sys.stderr)
+            raise SystemExit(3)
     eng.close()
 
     # ---- per-kernel durations (HIP events on the engine's stream), same start, separate run
     prof = {}
-    if args.profile_steps > 0:
-        engp = make_engine(1)
-        engp.run(args.warmup)
-        st, ps, _ = engp.run(args.profile_steps)
+    if profile_steps > 0:
+        engp = make_engine(1, make_fp())
+        engp.run(warmup)
+        st, ps, _ = engp.run(profile_steps)
         pd = ps.as_dict()
         for k, ms in pd["kernel_ms"].items():
             prof[k] = {"calls": int(pd["kernel_calls"][k]), "avg_us": 1e3 * ms / max(1, pd["kernel_calls"][k])}
         engp.close()
-
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank != 0:
-        return
-    # N>1: the ranks cooperate on ONE pivot stream (pricing sharded, the rest replicated)
-    pivots_per_s = args.steps / dt
-    price_bytes = 8.0 * ld * nN
-    if world > 1:  # each rank prices only its block of the nonbasic positions
+    out["prof"] = prof
+    # bytes the pricing launch of ONE rank streams (its column block)
+    price_cols = nN
+    if world > 1:
         from ellp_amd.dist import shard_ranges
         nt = 8.0 * ld * nN > 160e6
         cpb = max(1, min(64, (nN + 2047) // 2048 if nt else (nN + 1023) // 1024))
         a0, a1 = shard_ranges(nN, cpb, world)[0]
-        price_bytes = 8.0 * ld * (a1 - a0)
-    # HBM traffic of the pricing kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE, gfx950 x2 read correction) — only valid for the workload it was measured on
-    traffic = None
-    try:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
-            pm = json.load(open(f))
-            if pm.get("workload") != f"m={m} n={n} {args.solver}" or world != 1:
-                continue
-            want = "k_price<"
-            for kname, kv in pm["kernels"].items():
-                # k_price<T, MODE, NT> or k_price_wave<MODE>: pick the pricing kernel of this solver
-                mode = "1" if dual else "0"
-                if kname.startswith("k_price_wave<"):
-                    hit = kname[len("k_price_wave<"):].rstrip(">").strip() == mode
-                elif kname.startswith("k_price<"):
-                    hit = kname.split(",")[1].strip().rstrip(">") == mode
-                else:
-                    hit = False
-                if hit:
-                    traffic = kv["hbm_bytes_per_launch"]
-            if traffic is not None:
-                break
-    except Exception:
-        traffic = None
-    roofline = None
+        price_cols = a1 - a0
+    out["price_bytes"] = 8.0 * ld * price_cols
+    out["alg_bytes_per_pivot"] = 8.0 * ld * nN + (24.0 if dual else 32.0) * m * ld
+    # what the engine moves per iteration: BTRAN is O(m) incremental, and with the two-kernel pipeline
+    # the eta update and the next FTRAN share one pass over B^-1
+    return out
+
+
+def roofline_of(meas, m, n, solver, world):
+    dual = solver == "dual"
     pk = "dprice" if dual else "price"
-    if pk in prof:
-        t_us = prof[pk]["avg_us"]
-        ach = price_bytes / (t_us * 1e-6) / 1e9
-        roofline = {"kernel": "pricing pass (k_price_wave<%d> / k_price<T,%d,NT>)" % ((1, 1) if dual else (0, 0)), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes_per_launch": price_bytes, "avg_us": round(t_us, 3)}
+    prof = meas["prof"]
+    if pk not in prof:
+        return None
+    traffic, src = (None, None)
+    if world == 1:
+        traffic, src = pmc_traffic(m, n, solver, dual)
+    t_us = prof[pk]["avg_us"]
+    ach = meas["price_bytes"] / (t_us * 1e-6) / 1e9
+    return {"kernel": "pricing pass of one GPU (k_price*<%d>)" % (1 if dual else 0), "bound": "hbm",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc passes of an earlier run of this "
+                                                   "command, not measured in this run)") if src else None,
+            "bytes_per_launch": meas["price_bytes"], "avg_us": round(t_us, 3),
+            "avg_us_raw": round(t_us + prof.get("event_cost", {}).get("avg_us", 0.0), 3), "timing": EVENT_NOTE}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    ctx = Ctx()
+    if args.gpus > 1 and ctx.world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}")
+    ctx.init()
+    world, rank = ctx.world, ctx.rank
+    m, n = args.m, args.n
+    dual = args.solver == "dual"
+    is_c3 = (m, n, args.seed, args.solver) == (2000, 5000, 20260301, "primal")
+    want_c5 = args.config5 == 1 or (args.config5 < 0 and is_c3)
+    long_window = args.long_window if (args.steps < 1000 and args.long_window > 0) else 0
+
+    head = measure(ctx, args, m, n, args.seed, args.solver, args.steps, args.warmup, args.profile_steps, long_window)
+    c5 = None
+    if want_c5:
+        c5m = measure(ctx, args, 4000, 40000, 20260305, "primal", args.config5_steps, 100,
+                      min(args.profile_steps, 100))
+        if rank == 0:
+            r5 = roofline_of(c5m, 4000, 40000, "primal", world)
+            c5_bytes = c5m["alg_bytes_per_pivot"]
+            c5 = {"workload": f"random dense LP m=4000 n=40000 (seed 20260305), primal simplex phase 1, std-form "
+                              f"4000x{c5m['n_cols']} with |N|={c5m['nN']}, nonbasic columns sharded over {world} GPU(s)",
+                  "value": round(c5m["steps"] / c5m["dt"], 2), "unit": "pivots/s", "steps": c5m["steps"],
+                  "ms_per_step": round(1e3 * c5m["dt"] / c5m["steps"], 6),
+                  "pricing_GBps_per_gpu": r5["achieved"] if r5 else None,
+                  "pricing_frac_of_hbm_peak": r5["frac"] if r5 else None,
+                  "pricing_GBps_all_gpus": round(r5["achieved"] * world, 1) if r5 else None,
+                  "roofline": r5, "kernels_us": {k: round(v["avg_us"], 3) for k, v in c5m["prof"].items()},
+                  "achieved_GBps_algorithmic": round(c5_bytes * c5m["steps"] / c5m["dt"] / 1e9, 1),
+                  "sharded_check": c5m.get("sharded_check")}
+        del c5m
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
+    if rank != 0:
+        return
+    dt, steps = head["dt"], head["steps"]
+    pivots_per_s = steps / dt
+    flat = head["flat"]
+    roofline = roofline_of(head, m, n, args.solver, world)
     cpu = None
     cpu_pivots = args.cpu_pivots
     if cpu_pivots < 0:
@@ -259,23 +411,40 @@ def main():
                         "sample": f"first {it_c} pivots of the same LP from the same starting basis, {secs_c:.1f} s, "
                                   "oracle/ellp_oracle.c eo_%s_binv_solve_with_initial (explicit B^-1 + eta " % ("dual" if dual else "primal") +
                                   "updates like the engine, OpenMP over the host cores)"}
-    alg_bytes_per_pivot = 8.0 * ld * nN + (24.0 if dual else 32.0) * m * ld
+    ld, nN = head["ld"], head["nN"]
+    alg_bytes_per_pivot = head["alg_bytes_per_pivot"]
+    ms_per_step = 1e3 * dt / steps
+    alg_gbps = alg_bytes_per_pivot * steps / dt / 1e9
+    prof = head["prof"]
     out = {
         "metric": f"simplex pivots/sec (dense LP, {args.solver}, tableau resident in HBM)",
-        "value": round(pivots_per_s, 2), "unit": "pivots/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 6), "higher_is_better": True,
+        "value": round(pivots_per_s, 2), "unit": "pivots/s", "n_gpus": world, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"random dense covering LP m={m} n={n} (seed {args.seed}), dual simplex from the "
-                                f"slack basis, std-form {m}x{fp.n} with |N|={nN}" if dual else
+                                f"slack basis, std-form {m}x{head['n_cols']} with |N|={nN}" if dual else
                                 f"random dense LP m={m} n={n} (seed {args.seed}), primal simplex phase 1, "
-                                f"std-form {m}x{fp.n} with |N|={nN}"), "refactors_in_window": int(refactors),
-                   "inverse_residual_after": resid,
+                                f"std-form {m}x{head['n_cols']} with |N|={nN}"),
+                   "refactors_in_window": head["refactors"], "inverse_residual_after": head["resid"],
                    "parallelism": ("single GPU" if world == 1 else
-                                   f"column-block pricing sharded over {world} GPUs, 1 all-gather/iteration"),
-                   "sharded_check": sharded_check},
-        "achieved_GBps_algorithmic": round(alg_bytes_per_pivot * args.steps / dt / 1e9, 1),
-        "roofline": roofline, "cpu_baseline": cpu, "kernels_us": {k: round(v["avg_us"], 3) for k, v in prof.items()},
+                                   f"nonbasic columns (storage + pricing) sharded over {world} GPUs, one small "
+                                   "exchange per iteration; B^-1 and the point replicated"),
+                   "sharded_check": head.get("sharded_check")},
+        "achieved_GBps_algorithmic": round(alg_gbps, 1),
+        "iteration_roofline": {"bytes_per_step_algorithmic": alg_bytes_per_pivot,
+                               "achieved": round(alg_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(alg_gbps / HBM_PEAK_GBS, 4),
+                               "note": "SURVEY.md §8d bytes per pivot (8 m |N| + 32 m^2 primal, + 24 m^2 dual) / "
+                                       "ms_per_step; the engine itself moves less (BTRAN is an O(m) update)"},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "kernels_us": {k: round(v["avg_us"], 3) for k, v in prof.items()}, "kernels_us_note": EVENT_NOTE,
     }
+    if "long_window" in head:
+        lw = head["long_window"]
+        lw["vs_value"] = round(lw["value"] / pivots_per_s, 4)
+        out["long_window"] = lw
+    if c5 is not None:
+        out["config5"] = c5
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(pivots_per_s / cpu["value"], 1)
     if cpu_same:

@@ -27,7 +27,7 @@ class Opts(C.Structure):
     _fields_ = [("max_iter", C.c_uint64), ("eps", C.c_double), ("device", C.c_int32),
                 ("refactor_period", C.c_int32), ("btran_mode", C.c_int32),
                 ("poll_interval", C.c_int32), ("profile", C.c_int32), ("use_graph", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("pipeline", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Stats(C.Structure):
@@ -91,6 +91,10 @@ def lib():
     L.ellp_engine_inverse_residual.restype = C.c_double
     L.ellp_engine_inverse_residual.argtypes = [C.c_void_p]
     L.ellp_engine_destroy.argtypes = [C.c_void_p]
+    L.ellp_engine_request_maintenance.restype = C.c_int
+    L.ellp_engine_request_maintenance.argtypes = [C.c_void_p]
+    L.ellp_engine_debug_scale_inverse.restype = C.c_int
+    L.ellp_engine_debug_scale_inverse.argtypes = [C.c_void_p, C.c_double]
     L.ellp_engine_set_shard.restype = C.c_int
     L.ellp_engine_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
     L.ellp_engine_segment_doubles.restype = C.c_int64
@@ -258,6 +262,24 @@ class Engine:
 
     def inverse_residual(self):
         return lib().ellp_engine_inverse_residual(self._h)
+
+    def request_maintenance(self):
+        """test hook: what a kernel does after a tiny pivot (the next run()/poll() services it)"""
+        s = lib().ellp_engine_request_maintenance(self._h)
+        if s != OPTIMAL:
+            raise EllpHipError(s, "request_maintenance failed")
+
+    def debug_scale_inverse(self, factor):
+        """test hook: B^-1 <- factor * B^-1"""
+        s = lib().ellp_engine_debug_scale_inverse(self._h, float(factor))
+        if s != OPTIMAL:
+            raise EllpHipError(s, "debug_scale_inverse failed")
+
+    def counters(self):
+        """host-side maintenance counters (TAP_STATE tail)"""
+        v = self.tap(TAP_STATE, 20)
+        return dict(drift=v[12], drift_checks=int(v[13]), maint_requests=int(v[14]), refreshes=int(v[15]),
+                    rebuilds=int(v[16]), resyncs=int(v[17]), last_refresh_residual=v[18], launches_per_iteration=int(v[19]))
 
     # ---- sharded / stepped driving (see ellp_amd/dist.py)
     def segment_doubles(self, world):

@@ -89,6 +89,9 @@ struct DevState {
     // ---- results
     double lambda, obj;
     double drift;  // last k_drift_reduce: max|A_B (B^-1 a_q) - a_q| / max|a_q|
+    double resid;  // last Newton-Schulz refresh: max|I - A_B W| before the step (k_resid_reduce)
+    int32_t need_rebuild;  // that residual was too large for a Newton-Schulz step: the host must rebuild
+    int32_t pad_nr;
     unsigned long long iters, pivots, flips;
 #ifdef ELLP_DBG_STAMPS
     long long dbg[3][4][8];  // [kernel][block selector][stamp] wall_clock64 (100 MHz) — dev builds only
@@ -1699,6 +1702,7 @@ __global__ __launch_bounds__(256) void k_resync_xb(ResyncArgs a) {
 }
 __global__ __launch_bounds__(256) void k_resync_apply(ResyncArgs a) {
     if (a.st->status != ST_RUNNING && a.st->status != ST_NEED_MAINT) return;
+    if (a.st->need_rebuild) return;  // B^-1 failed its refresh: it is rebuilt first, then x_B is checked again
     const double maxdiff = __longlong_as_double((long long)a.maxbits[0]);
     const double maxx = __longlong_as_double((long long)a.maxbits[1]);
     if (!(maxdiff > 1e-11 * (1.0 + maxx)) || isinf(maxdiff)) return;
@@ -1881,6 +1885,7 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
     __shared__ double sB[BK][BN];
     __shared__ double s_red[4];
     if (a.st->status != ST_RUNNING) return;
+    if (STEP == 1 && a.st->need_rebuild) return;  // k_resid_reduce: not a small perturbation any more
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int64_t m = a.m, ld = a.ld;
@@ -1973,11 +1978,57 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs a) {
 
 // T -> W[cur^1], then cur ^= 1 (k_ref_finish)
 __global__ __launch_bounds__(256) void k_copy_to_other(GemmArgs a) {
-    if (a.st->status != ST_RUNNING) return;
+    if (a.st->status != ST_RUNNING || a.st->need_rebuild) return;
     double2 *dst = reinterpret_cast<double2 *>(a.st->cur ? a.W0 : a.W1);
     const double2 *src = reinterpret_cast<const double2 *>(a.T);
     const int64_t total = a.m * (a.ld >> 1);
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) dst[t] = src[t];
+}
+
+// residual of the refresh's first GEMM, folded on the device: max over the tile maxima of |I - A_B W|.
+// A Newton-Schulz step only converges from a small residual; at 1e-4 and beyond the step is skipped
+// (k_gemm128<1>, k_copy_to_other, k_refresh_finish test need_rebuild) and the loop is stopped with the
+// same request a tiny pivot raises, so that the host rebuilds B^-1 from A_B when it services it.
+// Deciding here instead of on the host keeps the stream from draining once per refresh.
+__global__ __launch_bounds__(256) void k_resid_reduce(GemmArgs a, int ntiles) {
+    __shared__ double s_r[4];
+    DevState *st = const_cast<DevState *>(a.st);
+    if (st->status != ST_RUNNING) return;
+    double w = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        const double v = a.tilemax[t];
+        w = (v > w || v != v) ? v : w;
+    }
+    // NaN-propagating maximum: once w is NaN every comparison below is false and it stays
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v = __shfl_xor(w, o);
+        w = (w != w) ? w : ((v > w || v != v) ? v : w);
+    }
+    if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            const double v = s_r[k];
+            w = (w != w) ? w : ((v > w || v != v) ? v : w);
+        }
+        st->resid = w;
+        if (!(w < 1e-4)) {
+            st->need_rebuild = 1;
+            st->tiny = 1;
+        }
+    }
+}
+__global__ void k_refresh_finish(GemmArgs a) {
+    DevState *st = const_cast<DevState *>(a.st);
+    if (st->status != ST_RUNNING || st->need_rebuild) return;
+    st->cur ^= 1;
+}
+
+__global__ __launch_bounds__(256) void k_scale_inverse(double *W0, double *W1, const DevState *st, int64_t total,
+                                                       double factor) {
+    double *W = st->cur ? W1 : W0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) W[t] *= factor;
 }
 
 // max |W A_B - I| (drift monitor, test/diagnostic only — m^3 work)
@@ -2017,6 +2068,29 @@ __global__ __launch_bounds__(256) void k_gather_cols(const double *A, int64_t m,
 __global__ __launch_bounds__(256) void k_gather_vec(const double *v, const int64_t *index, double *dst, int64_t n) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k < n) dst[k] = v[index[k]];
+}
+
+// c . x for a primal engine (standard_form.rs:48), from the gathered costs: sum_i c_B[i] x[B_i] +
+// sum_j c_N[j] x[N_j]; one block, fixed reduction order.  Only for ellp_stats.obj (the loop never
+// needs it: the reference computes it outside the loop too, primal…:42-45).
+__global__ __launch_bounds__(1024) void k_primal_obj(const double *c_B, const double *c_N, const double *x,
+                                                    const int64_t *B_index, const int64_t *N_index, int64_t m,
+                                                    int64_t nN, DevState *st) {
+    __shared__ double s_p[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) acc = fma(c_B[i], x[B_index[i]], acc);
+    for (int64_t j = threadIdx.x; j < nN; j += 1024) {
+        const double cj = c_N[j];
+        if (cj != 0.0) acc = fma(cj, x[N_index[j]], acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_p[w];
+        st->obj = t;
+    }
 }
 
 // phase hand-off (ellp_engine_rephase): re-gather the costs by the current index sets and relabel the
@@ -2093,6 +2167,8 @@ struct ellp_engine {
     size_t upd_lds = 0, ftran_lds = 0;
     // loop bookkeeping
     uint64_t since_refactor = 0, since_btran = 0;
+    uint64_t enqueued = 0;  // iterations enqueued since the counters were last reconciled with DevState::iters
+    uint64_t iters_seen = 0;  // DevState::iters at that moment
     int refactor_period = 0;
     int btran_refresh = 32;
     uint64_t refactors = 0;
@@ -2314,30 +2390,22 @@ void launch_refactor(ellp_engine *e) {
     e->u_valid = false;
 }
 
-// One Newton-Schulz step on the current inverse.  Returns the residual max|I - A_B W| measured
-// BEFORE the step (host readback: one sync per refresh), or a negative value on a HIP error.
-// If the residual is too large for the iteration to be trusted the caller rebuilds instead.
-double launch_refresh(ellp_engine *e) {
+// One Newton-Schulz step on the current inverse, enqueued without any host synchronisation: the
+// residual max|I - A_B W| of the first GEMM is folded on the device (k_resid_reduce), which also
+// decides whether the step is safe; if it is not, the step is skipped, DevState::need_rebuild is set
+// and the loop stops with a maintenance request that the host services by rebuilding from A_B.
+void launch_refresh(ellp_engine *e) {
     Prof p(e, ELLP_K_REFACTOR);
     GemmArgs a{e->W, e->W2, e->A_B, e->T, e->resid, e->st, e->m, e->ld};
     const unsigned nt = (unsigned)((e->m + 127) / 128);
     hipLaunchKernelGGL(k_gemm128<0>, dim3(nt, nt), dim3(256), 0, e->stream, a);
-    std::vector<double> tm((size_t)nt * nt);
-    if (hipMemcpyAsync(tm.data(), e->resid, sizeof(double) * tm.size(), hipMemcpyDeviceToHost, e->stream) != hipSuccess)
-        return -1.0;
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return -1.0;
-    double res = 0.0;
-    for (double v : tm) res = (v > res || v != v) ? v : res;
-    e->last_residual = res;
-    if (!(res < 1e-4)) return res;  // not a small perturbation any more: let the caller rebuild
+    hipLaunchKernelGGL(k_resid_reduce, dim3(1), dim3(256), 0, e->stream, a, (int)(nt * nt));
     hipLaunchKernelGGL(k_gemm128<1>, dim3(nt, nt), dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_copy_to_other, dim3(1024), dim3(256), 0, e->stream, a);
-    RefArgs ra{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows, e->eps};
-    hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, e->stream, ra);
+    hipLaunchKernelGGL(k_refresh_finish, dim3(1), dim3(1), 0, e->stream, a);
     e->refreshes += 1;
     e->since_refactor = 0;
     e->u_valid = false;
-    return res;
 }
 
 // Default maintenance period, from a cost model: a refresh costs T_r ~ 2*(2 m^3)/25 TFLOP/s + 60 us
@@ -2395,28 +2463,52 @@ void launch_resync(ellp_engine *e) {
 // against the fresh inverse (launch_resync).  `reactive` (asked for by the device, or the follow-up of
 // such a request) is kept for diagnostics: resynchronising only then was tried and is worse (netlib
 // ADLITTLE / BLEND in 60 variable orders, dual: 4 wrong outcomes instead of 1).
-void maintain_inverse(ellp_engine *e, bool reactive = false) {
-    const double res = launch_refresh(e);
-    if (!(res >= 0.0 && res < 1e-4)) launch_refactor(e);
+void maintain_inverse(ellp_engine *e, bool reactive = false, bool rebuild = false) {
+    if (rebuild) launch_refactor(e);
+    else launch_refresh(e);
     const char *mode = getenv("ELLP_RESYNC");  // diagnostics: "0" never, "1" only on reactive maintenance
     const bool want = mode && mode[0] == '0' ? false : (mode && mode[0] == '1' ? reactive : true);
     if (want) launch_resync(e);
 }
 
+// After a read-back with the stream drained: iterations that were enqueued behind a stop (a final
+// status or a maintenance request) returned at entry and did not happen, but the host counted them
+// when it enqueued them.  Take them back, so that the maintenance schedule follows the iterations
+// that really ran (DevState::iters counts every loop body entered).
+void reconcile_counters(ellp_engine *e) {
+    const uint64_t ran = e->h_st->iters >= e->iters_seen ? e->h_st->iters - e->iters_seen : 0;
+    const uint64_t lost = e->enqueued > ran ? e->enqueued - ran : 0;
+    if (lost) {
+        e->since_refactor = e->since_refactor > lost ? e->since_refactor - lost : 0;
+        e->since_btran = e->since_btran > lost ? e->since_btran - lost : 0;
+        e->since_drift = e->since_drift > lost ? e->since_drift - lost : 0;
+    }
+    e->enqueued = 0;
+    e->iters_seen = e->h_st->iters;
+}
+
 // After a status read-back: if a kernel asked for maintenance, do it, re-arm the loop and report
-// true (the caller keeps going).  The flagged iteration committed nothing, so it is simply redone.
+// true (the caller keeps going).  The pivot that raised the request is committed (k_update2 raises the
+// flag after its bookkeeping); what is void is the rest of the batch behind it.  The device is
+// re-armed (status = RUNNING, tiny = 0) BEFORE the maintenance kernels are enqueued: all of them
+// (k_gemm128, k_copy_to_other, k_ref_*, k_dleave) return at entry on any other status, so servicing
+// the request under ST_NEED_MAINT would refresh nothing and re-select the dual's leaving row from
+// nothing.
 bool service_maintenance_request(ellp_engine *e) {
     // the request is the status (a later pricing launch of the batch saw the flag) or still the flag
     // (the batch ended with the k_update2 that raised it)
     if (e->h_st->status != ST_NEED_MAINT && !(e->h_st->status == ST_RUNNING && e->h_st->tiny)) return false;
-    maintain_inverse(e, true);
-    e->maint_chain = 1;
     const int32_t running = ST_RUNNING, zero = 0;
+    const bool rebuild = e->h_st->need_rebuild != 0;  // a refresh found B^-1 too far off for Newton-Schulz
     (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     (void)hipMemcpyAsync(&e->st->tiny, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
-    (void)hipStreamSynchronize(e->stream);
+    (void)hipMemcpyAsync(&e->st->need_rebuild, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     e->h_st->status = ST_RUNNING;
     e->h_st->tiny = 0;
+    e->h_st->need_rebuild = 0;
+    maintain_inverse(e, true, rebuild);
+    e->maint_chain = 1;
+    (void)hipStreamSynchronize(e->stream);
     e->maint_requests += 1;
     return true;
 }
@@ -2457,6 +2549,7 @@ void launch_primal_iteration(ellp_engine *e) {
     }
     e->since_btran += 1;
     e->since_refactor += 1;
+    e->enqueued += 1;
 }
 
 void launch_dual_iteration(ellp_engine *e) {
@@ -2474,6 +2567,7 @@ void launch_dual_iteration(ellp_engine *e) {
         launch_update2<1>(e, 0);
     }
     e->since_refactor += 1;
+    e->enqueued += 1;
 }
 
 void launch_dleave(ellp_engine *e) {
@@ -2511,6 +2605,34 @@ double host_dual_obj(int64_t m, int64_t n_c, const double *b, const uint8_t *kin
         }
     }
     return obj;
+}
+
+// ellp_stats from the last read-back; for a primal engine obj = c.x is computed now (one small launch)
+void fill_stats(ellp_engine *e, ellp_stats *stats) {
+    if (!stats) return;
+    memset(stats, 0, sizeof(*stats));
+    stats->iters = e->h_st->iters;
+    stats->pivots = e->h_st->pivots;
+    stats->bound_flips = e->h_st->flips;
+    stats->refactors = e->refactors + e->refreshes;
+    stats->obj = e->h_st->obj;
+    if (e->kind == ELLP_ENGINE_PRIMAL && e->st) {
+        hipLaunchKernelGGL(k_primal_obj, dim3(1), dim3(1024), 0, e->stream, e->c_B, e->c_N, e->x, e->B_index,
+                           e->N_index, e->m, e->nN, e->st);
+        double v = 0.0;
+        if (hipMemcpyAsync(&v, &e->st->obj, sizeof(double), hipMemcpyDeviceToHost, e->stream) == hipSuccess &&
+            hipStreamSynchronize(e->stream) == hipSuccess)
+            stats->obj = v;
+    }
+    stats->t_setup_s = e->t_setup;
+    for (int k = 0; k < ELLP_K_COUNT; ++k) {
+        stats->kernel_ms[k] = e->kernel_ms[k];
+        stats->kernel_calls[k] = e->kernel_calls[k];
+    }
+    if (e->opts.profile && e->ev_overhead_ms >= 0.0) {
+        stats->kernel_ms[ELLP_K_EVENT_COST] = e->ev_overhead_ms;
+        stats->kernel_calls[ELLP_K_EVENT_COST] = 1;
+    }
 }
 
 }  // namespace
@@ -2741,6 +2863,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->bidx, (size_t)m));
     ECHK(dmalloc(e, &e->dpos, (size_t)m));
     ECHK(dmalloc(e, &e->resid, (size_t)(m > 4096 ? m : 4096)));
+    ECHK(hipMemsetAsync(e->resid, 0, sizeof(double) * (size_t)(m > 4096 ? m : 4096), e->stream));
     ECHK(dmalloc(e, &e->T, (size_t)(m * ld)));
     ECHK(hipMemsetAsync(e->T, 0, sizeof(double) * (size_t)(m * ld), e->stream));
     ECHK(dmalloc(e, &e->st, 1));
@@ -2847,9 +2970,20 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
 double ellp_engine_refresh(ellp_engine *e) {
     if (!e) return NAN;
     if (hipSetDevice(e->device) != hipSuccess) return NAN;
-    const double res = launch_refresh(e);
-    (void)hipStreamSynchronize(e->stream);
+    launch_refresh(e);
+    if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return NAN;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return NAN;
     prof_collect(e);
+    const double res = e->h_st->resid;
+    e->last_residual = res;
+    if (e->h_st->need_rebuild) {  // an explicit refresh that was refused changes nothing and stops nothing
+        const int32_t zero = 0;
+        (void)hipMemcpyAsync(&e->st->need_rebuild, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        (void)hipMemcpyAsync(&e->st->tiny, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+        e->h_st->need_rebuild = 0;
+        e->h_st->tiny = 0;
+    }
     return res;
 }
 
@@ -2888,6 +3022,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         // a previous slice may already have terminated
         HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
+        reconcile_counters(e);
         if (e->h_st->status != ST_RUNNING) {
             result = status_message(*e->h_st, errbuf, errlen);
             remaining = 0;
@@ -2937,6 +3072,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
                 HIPCHK(hipStreamSynchronize(e->stream));
                 HIPCHK(hipGetLastError());
+                reconcile_counters(e);
                 const uint64_t done = e->h_st->iters - iters0;
                 remaining = done < max_iters ? max_iters - done : 0;
                 if (service_maintenance_request(e)) continue;  // refreshed; the follow-up runs in the loop below
@@ -2954,6 +3090,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             HIPCHK(hipStreamSynchronize(e->stream));
             HIPCHK(hipGetLastError());
             prof_collect(e);
+            reconcile_counters(e);
             // iterations that really ran (a maintenance request voids the rest of its batch)
             const uint64_t done = e->h_st->iters - iters0;
             remaining = done < max_iters ? max_iters - done : 0;
@@ -2964,22 +3101,8 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         }
     }
     if (stats) {
-        memset(stats, 0, sizeof(*stats));
-        stats->iters = e->h_st->iters;
-        stats->pivots = e->h_st->pivots;
-        stats->bound_flips = e->h_st->flips;
-        stats->refactors = e->refactors + e->refreshes;
-        stats->obj = e->h_st->obj;
+        fill_stats(e, stats);
         stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        stats->t_setup_s = e->t_setup;
-        for (int k = 0; k < ELLP_K_COUNT; ++k) {
-            stats->kernel_ms[k] = e->kernel_ms[k];
-            stats->kernel_calls[k] = e->kernel_calls[k];
-        }
-        if (e->opts.profile && e->ev_overhead_ms >= 0.0) {
-            stats->kernel_ms[ELLP_K_EVENT_COST] = e->ev_overhead_ms;
-            stats->kernel_calls[ELLP_K_EVENT_COST] = 1;
-        }
     }
     return result;
 }
@@ -3031,6 +3154,15 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
         if (cap >= 14) {  // + last drift estimate of B^-1 (k_drift_reduce) and the number of checks so far
             dst[12] = h.drift;
             dst[13] = (double)e->drift_checks;
+            if (cap >= 20) {
+                dst[14] = (double)e->maint_requests;
+                dst[15] = (double)e->refreshes;
+                dst[16] = (double)e->refactors;
+                dst[17] = (double)e->resyncs;
+                dst[18] = h.resid;
+                dst[19] = 3.0;
+                return 20;
+            }
             return 14;
         }
         return 12;
@@ -3057,6 +3189,25 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
         if (hipStreamSynchronize(e->stream) != hipSuccess) return ELLP_ERR_DEVICE;
     }
     return count;
+}
+
+ellp_status ellp_engine_request_maintenance(ellp_engine *e) {
+    if (!e) return ELLP_ERR_ARG;
+    if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    const int32_t one = 1;
+    if (hipMemcpyAsync(&e->st->tiny, &one, sizeof(int32_t), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+        return ELLP_ERR_DEVICE;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_debug_scale_inverse(ellp_engine *e, double factor) {
+    if (!e) return ELLP_ERR_ARG;
+    if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    hipLaunchKernelGGL(k_scale_inverse, dim3(512), dim3(256), 0, e->stream, e->W, e->W2, e->st, e->m * e->ld, factor);
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return ELLP_ERR_DEVICE;
+    e->u_valid = false;
+    return ELLP_OPTIMAL;
 }
 
 double ellp_engine_inverse_residual(ellp_engine *e) {
@@ -3175,6 +3326,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
             launch_update2<1>(e, 0);
         }
         e->since_refactor += 1;
+        e->enqueued += 1;
     }
     HIPCHK(hipGetLastError());
     return ELLP_OPTIMAL;
@@ -3186,24 +3338,9 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
     HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     prof_collect(e);
+    reconcile_counters(e);
     (void)service_maintenance_request(e);
-    if (stats) {
-        memset(stats, 0, sizeof(*stats));
-        stats->iters = e->h_st->iters;
-        stats->pivots = e->h_st->pivots;
-        stats->bound_flips = e->h_st->flips;
-        stats->refactors = e->refactors + e->refreshes;
-        stats->obj = e->h_st->obj;
-        stats->t_setup_s = e->t_setup;
-        for (int k = 0; k < ELLP_K_COUNT; ++k) {
-            stats->kernel_ms[k] = e->kernel_ms[k];
-            stats->kernel_calls[k] = e->kernel_calls[k];
-        }
-        if (e->opts.profile && e->ev_overhead_ms >= 0.0) {
-            stats->kernel_ms[ELLP_K_EVENT_COST] = e->ev_overhead_ms;
-            stats->kernel_calls[ELLP_K_EVENT_COST] = 1;
-        }
-    }
+    fill_stats(e, stats);
     if (e->h_st->status == ST_RUNNING) return ELLP_MAXITER;  // still running: the slice is simply used up
     return status_message(*e->h_st, errbuf, errlen);
 }
@@ -3255,6 +3392,8 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     (void)hipFree(c_dev);
     e->u_valid = false;  // u = B^-T c_B with the new costs
     e->maint_chain = 0;
+    e->enqueued = 0;
+    e->iters_seen = 0;
     return ELLP_OPTIMAL;
 }
 

@@ -69,7 +69,10 @@ typedef struct ellp_opts {
     int32_t profile;         /* != 0: bracket every launch with HIP events (ellp_stats.kernel_ms) */
     int32_t use_graph;       /* reserved, must be 0 (hipGraph replay of the launch sequence is not implemented:
                                 on gfx950 the per-iteration cost is GPU-side dispatch, not host launches) */
-    int32_t reserved[4];
+    int32_t pipeline;        /* launches per primal iteration: 0 = engine default, 1 = three (pricing | FTRAN |
+                                eta update), 2 = two (pricing | eta update of the previous pivot fused with this
+                                iteration's FTRAN: one pass over B^-1 instead of two) */
+    int32_t reserved[3];
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */
@@ -221,7 +224,10 @@ ellp_status ellp_engine_run_sharded(ellp_engine *e, uint64_t max_iters, ellp_sta
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
 enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,
-       ELLP_TAP_ALPHA = 5, ELLP_TAP_STATE = 6 /* 12 doubles: status,cur,s_q,s_r,theta_d,delta,lr,ldelta,iters,pivots,lambda,rq */ };
+       ELLP_TAP_ALPHA = 5, ELLP_TAP_STATE = 6 /* 12 doubles: status,cur,s_q,s_r,theta_d,delta,lr,ldelta,iters,pivots,lambda,rq;
+                                                  cap >= 14: + drift, drift checks; cap >= 20: + maintenance requests
+                                                  serviced, Newton-Schulz refreshes, rebuilds, x_B resyncs, last
+                                                  refresh residual, launches per primal iteration */ };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
 /* One Newton-Schulz step W <- W + W (I - A_B W) on the resident inverse (two f64 GEMMs); this
@@ -231,6 +237,15 @@ double ellp_engine_refresh(ellp_engine *e);
 
 /* Forces a full rebuild of B^-1 from A_B now (used by tests and when a refresh is not safe). */
 ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errbuf_len);
+
+/* Test / diagnostic hook: raises the maintenance request a kernel raises after a tiny pivot or a
+ * drift-monitor hit (DevState::tiny), as if the last iteration had asked for it.  The next run()/poll()
+ * services it: B^-1 is refreshed (and x_B re-checked) before any further iteration. */
+ellp_status ellp_engine_request_maintenance(ellp_engine *e);
+
+/* Test hook: multiplies the resident B^-1 by `factor` (a damaged inverse, to exercise the path on
+ * which a refresh is refused and the host rebuilds from A_B). */
+ellp_status ellp_engine_debug_scale_inverse(ellp_engine *e, double factor);
 
 /* max_ij |(B^-1 A_B - I)_ij| computed on device (drift monitor; tests). */
 double ellp_engine_inverse_residual(ellp_engine *e);

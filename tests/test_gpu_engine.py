@@ -95,6 +95,20 @@ def test_primal_known_answers(fx):
             np.testing.assert_allclose(fp2.x[:len(fx["x"])], fx["x"], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
+def test_primal_known_answers_default_maintenance(fx):
+    """The same 25 fixtures, pivot for pivot, on the engine exactly as a user gets it: default
+    maintenance (Newton-Schulz refresh every 16 iterations at this size, reactive maintenance after
+    tiny pivots, x_B re-checked against the fresh inverse)."""
+    out = primal_two_phase(fx)
+    if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj"):
+        status, fp2 = out
+        assert status == "optimal"
+        assert abs(fp2.obj() - fx["obj"]) < 1e-8
+        if fx["check"] == "optimal":
+            np.testing.assert_allclose(fp2.x[:len(fx["x"])], fx["x"], rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize("fx", KA["netlib"], ids=[p["name"] for p in KA["netlib"]])
 def test_primal_netlib(fx):
     prob_fx = read_mps(os.path.join(GOLDEN, fx["file"]))
@@ -162,6 +176,17 @@ def test_dual_known_answers(fx):
             np.testing.assert_allclose(fp2.x[:len(fx["x"])], fx["x"], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
+def test_dual_known_answers_default_maintenance(fx):
+    """The 25 fixtures through the dual loop, pivot for pivot, with the default maintenance."""
+    out = dual_two_phase(fx)
+    if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj") and out[0] == "optimal":
+        status, fp2 = out
+        assert abs(fp2.obj() - fx["obj"]) < 1e-8
+        if fx["check"] == "optimal":
+            np.testing.assert_allclose(fp2.x[:len(fx["x"])], fx["x"], rtol=0, atol=1e-8)
+
+
 @pytest.mark.parametrize("fx", KA["netlib"], ids=[p["name"] for p in KA["netlib"]])
 def test_dual_netlib(fx):
     prob_fx = read_mps(os.path.join(GOLDEN, fx["file"]))
@@ -197,6 +222,71 @@ def test_newton_schulz_refresh_restores_the_inverse():
     eng.close()
     assert st == E.OPTIMAL, msg
     assert abs(fp.obj()) < 1e-8  # phase 1 of a feasible LP ends at objective 0
+
+
+@pytest.mark.parametrize("kind", ["primal", "dual"])
+def test_maintenance_request_is_serviced_at_once(kind):
+    """A maintenance request raised mid-batch (what k_update2 does after a tiny pivot, what the drift
+    monitor does) must refresh B^-1 BEFORE the next iteration runs: the maintenance kernels return
+    at entry unless the status is RUNNING, so the host has to re-arm the device first (round-1 bug:
+    it serviced the request under ST_NEED_MAINT and the refresh was a no-op).  Checked on the
+    residual max|W A_B - I|: drifted by 300 eta updates, it must be back at rounding level after the
+    one iteration that follows the request, with exactly one request serviced and the dual's leaving
+    row re-selected (the run continues to the optimum)."""
+    E = _engine()
+    from ellp_amd import synth
+    if kind == "primal":
+        f = synth.primal_phase1_flat(20260301, 200, 500)
+        ek = E.ENGINE_PRIMAL
+    else:
+        f = synth.dual_start_flat(20260301, 150, 400)
+        ek = E.ENGINE_DUAL
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                       f["x"], f["B"], f["N"], f["Nb"], f.get("y"), f.get("d"))
+    eng = E.Engine(ek, fp, E.default_opts(max_iter=None, refactor_period=1 << 30))
+    st, stats, _ = eng.run(300)
+    assert st == E.MAXITER and stats.iters == 300
+    before = eng.inverse_residual()
+    c0 = eng.counters()
+    eng.request_maintenance()
+    st, stats, msg = eng.run(1)
+    assert st == E.MAXITER and stats.iters == 301, msg
+    after = eng.inverse_residual()
+    c1 = eng.counters()
+    assert c1["maint_requests"] == c0["maint_requests"] + 1
+    assert c1["refreshes"] >= c0["refreshes"] + 1 and c1["resyncs"] >= c0["resyncs"] + 1
+    assert 0.0 < c1["last_refresh_residual"] < 1e-6
+    assert after < 0.2 * before and after < 5e-14, (before, after)
+    st, stats, msg = eng.run(1 << 40)
+    eng.read_point()
+    eng.close()
+    assert st == E.OPTIMAL, msg
+
+
+def test_refused_refresh_leads_to_a_rebuild():
+    """A Newton-Schulz step only converges from a small residual.  The decision is taken on the
+    device: with B^-1 replaced by garbage the refresh must refuse (need_rebuild), stop the loop with a
+    maintenance request, and the host must rebuild from A_B when it services it."""
+    E = _engine()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(20260301, 120, 300)
+    ref = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                        f["x"], f["B"], f["N"], f["Nb"])
+    st_r, stats_r, _ = E.primal_solve_with_initial(ref, E.default_opts(max_iter=None))
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                       f["x"], f["B"], f["N"], f["Nb"])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, refactor_period=40))
+    eng.run(30)
+    eng.debug_scale_inverse(1.5)      # W <- 1.5 W: residual 0.5, far outside Newton-Schulz's basin
+    assert eng.inverse_residual() > 0.4
+    c0 = eng.counters()
+    st, stats, msg = eng.run(1 << 40)  # the periodic refresh at iteration 40 refuses, the host rebuilds
+    c1 = eng.counters()
+    eng.read_point()
+    eng.close()
+    assert st == E.OPTIMAL, msg
+    assert c1["rebuilds"] >= c0["rebuilds"] + 1
+    assert abs(fp.obj()) < 1e-8
 
 
 def test_default_maintenance_period_full_solve():

@@ -274,10 +274,40 @@ def _permuted(fx, rng):
             "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
 
 
+def netlib_order_case(base, ka, fx, trial, bad):
+    """One variable/constraint order of a netlib LP: primal phase by phase pivot for pivot against the
+    oracle (a degenerate tie may fall the other way: same objective then), dual phase by phase to the
+    same status and objective; both must end at the pinned optimum (tests/problems/mod.rs:658-672).
+    Returns the number of primal phase runs that took another tie path."""
+    prob = eo.Problem.from_fixture(fx)
+    p1, err = eo.primal_phase1(prob)
+    r = seam(p1.view(), "primal", 5000)
+    compare((trial, "primal1"), *r, bad)
+    assert r[1] == r[4] == eo.OPTIMAL and abs(r[0].obj()) < 1e-10 and abs(r[3].obj()) < 1e-9, (trial, r[1], r[4], r[7])
+    p1.store_point(r[0])
+    r2 = seam(eo.primal_phase2(p1).view(), "primal", 5000)
+    compare((trial, "primal2"), *r2, bad)
+    assert r2[1] == r2[4] == eo.OPTIMAL and abs(r2[3].obj() / ka["obj"] - 1.0) < 1e-6, (trial, r2[1], r2[4], r2[7])
+    # dual, at the seam: same status and objective
+    d1, err = eo.dual_phase1(prob)
+    rd = seam(d1.view(), "dual", 20000)
+    assert rd[1] == rd[4] == eo.OPTIMAL, (trial, "dual1", rd[1], rd[4], rd[7])
+    d1.store_point(rd[0])
+    d2, err2 = eo.dual_phase2(d1)
+    assert d2 is not None and not err2
+    rd2 = seam(d2.view(), "dual", 20000)
+    assert rd2[1] == rd2[4] == eo.OPTIMAL, (trial, "dual2", rd2[1], rd2[4], rd2[7])
+    assert abs(rd2[3].obj() / ka["obj"] - 1.0) < 1e-6 and abs(rd2[0].obj() / ka["obj"] - 1.0) < 1e-6, (trial, rd2[3].obj())
+
+
+NETLIB_ORDERS = 60
+
+
 @pytest.mark.parametrize("name", ["afiro", "adlittle", "blend"])
 def test_netlib_in_random_orders(name):
-    """Real, sparse, degenerate LPs in 6 random variable/constraint orders each: primal phase by phase
-    pivot for pivot against the oracle, and the pinned optimum (tests/problems/mod.rs:658-672) at the
+    """Real, sparse, degenerate LPs in 60 random variable/constraint orders each (the size of the
+    campaign that found the round-1 dual failures; the reference iterates HashMaps, so every order
+    occurs): primal phase by phase pivot for pivot against the oracle, and the pinned optimum at the
     end, for the primal loop and for the dual loop (objective only: exact-minimum ties)."""
     import os
     from helpers import GOLDEN, known_answers, read_mps
@@ -285,31 +315,41 @@ def test_netlib_in_random_orders(name):
     base = read_mps(os.path.join(GOLDEN, ka["file"]))
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    n_paths = 0
-    for trial in range(6):
+    bad = []
+    for trial in range(NETLIB_ORDERS):
         fx = _permuted(base, rng)
-        prob = eo.Problem.from_fixture(fx)
-        # primal, at the seam
-        p1, err = eo.primal_phase1(prob)
-        bad = []
-        r = seam(p1.view(), "primal", 5000)
-        compare((trial, "primal1"), *r, bad)
-        assert r[1] == r[4] == eo.OPTIMAL and abs(r[0].obj()) < 1e-10 and abs(r[3].obj()) < 1e-9
-        p1.store_point(r[0])
-        r2 = seam(eo.primal_phase2(p1).view(), "primal", 5000)
-        compare((trial, "primal2"), *r2, bad)
-        assert r2[1] == r2[4] == eo.OPTIMAL and abs(r2[3].obj() / ka["obj"] - 1.0) < 1e-6
-        # pivot for pivot except where a degenerate tie falls the other way (same objective then)
-        assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
-        n_paths += len(bad)
-        # dual, at the seam: same status and objective
-        d1, err = eo.dual_phase1(prob)
-        rd = seam(d1.view(), "dual", 20000)
-        assert rd[1] == rd[4] == eo.OPTIMAL, (trial, rd[1], rd[4], rd[7])
-        d1.store_point(rd[0])
-        d2, err2 = eo.dual_phase2(d1)
-        assert d2 is not None and not err2
-        rd2 = seam(d2.view(), "dual", 20000)
-        assert rd2[1] == rd2[4] == eo.OPTIMAL, (trial, rd2[1], rd2[4], rd2[7])
-        assert abs(rd2[3].obj() / ka["obj"] - 1.0) < 1e-6 and abs(rd2[0].obj() / ka["obj"] - 1.0) < 1e-6
-    assert n_paths <= 3, n_paths  # of 12 primal phase runs
+        netlib_order_case(base, ka, fx, trial, bad)
+    # pivot for pivot except where a degenerate tie falls the other way (same objective then)
+    assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
+    assert len(bad) <= 0.25 * 2 * NETLIB_ORDERS, len(bad)  # of 2 primal phase runs per order
+
+
+def _regression_orders():
+    import json
+    import os
+    from helpers import GOLDEN
+    path = os.path.join(GOLDEN, "netlib_orders.json")
+    if not os.path.exists(path):
+        return []
+    with open(path) as f:
+        return json.load(f)["orders"]
+
+
+@pytest.mark.parametrize("case", _regression_orders(), ids=lambda c: f"{c['name']}-{c['tag']}")
+def test_netlib_regression_orders(case):
+    """Variable/constraint orders of the netlib LPs on which an earlier engine ended wrongly
+    (tests/golden/netlib_orders.json: the permutations themselves, found by tools/netlib_orders.py);
+    each must now end at the pinned optimum through both loops."""
+    import os
+    from helpers import GOLDEN, known_answers, read_mps
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == case["name"])
+    base = read_mps(os.path.join(GOLDEN, ka["file"]))
+    perm = case["var_perm"]
+    inv = np.empty(len(perm), dtype=int)
+    inv[np.asarray(perm)] = np.arange(len(perm))
+    rows = [base["constraints"][i] for i in case["row_perm"]]
+    fx = {"vars": [base["vars"][j] for j in perm],
+          "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
+    bad = []
+    netlib_order_case(base, ka, fx, case["tag"], bad)
+    assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
