@@ -18,7 +18,8 @@ HOST_LIB = os.path.join(HERE, "libellp_host.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-            "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-function", "-I" + INCLUDE]
+            "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-function", "-I" + INCLUDE,
+            "-I" + os.path.join(HERE, "csrc", "engine")]
 
 
 def _stale(target, sources):
@@ -30,7 +31,9 @@ def _stale(target, sources):
 
 def _deps(extra):
     hdrs = [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
-    return list(extra) + hdrs
+    edir = os.path.join(HERE, "csrc", "engine")
+    incs = [os.path.join(edir, f) for f in os.listdir(edir) if f.endswith(".inc")]
+    return list(extra) + hdrs + incs
 
 
 def build_engine(force=False, verbose=False):

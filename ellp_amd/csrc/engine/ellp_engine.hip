@@ -2107,6 +2107,8 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
     }
 }
 
+#include "ellp_small.inc"
+
 }  // namespace
 
 // ====================================================================== host side
@@ -2150,6 +2152,10 @@ struct ellp_engine {
     int64_t seg = 0;
     hipStream_t own_stream = nullptr;
     bool need_dleave = true;
+    // small LPs (m <= 128): the reference's LU-per-iteration loop in one persistent workgroup (ellp_small.inc)
+    bool small = false;      // run() uses k_small
+    bool w_valid = true;     // the explicit inverse W (not kept by k_small) matches A_B
+    size_t small_lds = 0;
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
     int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
@@ -2583,6 +2589,10 @@ ellp_status status_message(const DevState &s, char *errbuf, size_t errlen) {
     case ELLP_ERR_PANIC:
         if (s.panic_code == 402) set_err(errbuf, errlen, "assertion failed: lambda >= 0.");
         else if (s.panic_code == 229) set_err(errbuf, errlen, "pivot should have been unbounded");
+        else if (s.panic_code == 187) set_err(errbuf, errlen, "unwrap() on None in BTRAN");
+        else if (s.panic_code == 295) set_err(errbuf, errlen, "unwrap() on None in FTRAN");
+        else if (s.panic_code == 249) set_err(errbuf, errlen, "unwrap() on None in dual BTRAN");
+        else if (s.panic_code == 294) set_err(errbuf, errlen, "unwrap() on None in dual FTRAN");
         else set_err(errbuf, errlen, "reference invariant violated (code %d)", s.panic_code);
         break;
     default: break;
@@ -2950,8 +2960,34 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
             }
         }
     }
-    // initial B^-1
-    launch_refactor(e);
+    // small LPs: the reference's own loop in one persistent workgroup (ellp_small.inc) unless the caller
+    // asked for the explicit-inverse engine (a maintenance period, a launch structure, profiling)
+    {
+        const int pl = e->opts.pipeline;
+        e->small_lds = small_lds_bytes(m, n_N);
+        const bool wanted = pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
+                                        e->opts.profile == 0);
+        if (pl == 3 && e->small_lds == 0) {
+            set_err(errbuf, errlen, "pipeline 3 (one persistent workgroup) needs m <= %d and its LU in LDS", SMALL_MAX_M);
+            ellp_engine_destroy(e);
+            return ELLP_ERR_ARG;
+        }
+        e->small = wanted && e->small_lds > 0;
+        if (e->small) {
+            hipError_t ra = e->kind == ELLP_ENGINE_PRIMAL
+                                ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small<0>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->small_lds)
+                                : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small<1>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->small_lds);
+            if (ra != hipSuccess) {
+                (void)hipGetLastError();
+                e->small = false;  // the large engine handles it
+            }
+        }
+    }
+    // initial B^-1 (k_small keeps none: its LU is redone every iteration, with the reference's guard)
+    if (e->small) e->w_valid = false;
+    else launch_refactor(e);
     ECHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     ECHK(hipStreamSynchronize(e->stream));
     ECHK(hipGetLastError());
@@ -2967,9 +3003,63 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     return ELLP_OPTIMAL;
 }
 
+// The explicit-inverse engine is about to be used on an engine that has been running k_small: build
+// B^-1 from the current A_B and leave the small path for good.
+static ellp_status ensure_inverse(ellp_engine *e, char *errbuf, size_t errlen) {
+    if (e->w_valid) {
+        e->small = false;
+        return ELLP_OPTIMAL;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    launch_refactor(e);
+    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    prof_collect(e);
+    e->w_valid = true;
+    e->small = false;
+    e->need_dleave = true;
+    e->u_valid = false;
+    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    return ELLP_OPTIMAL;
+}
+
+// ellp_engine_run for the small path: launches of k_small, each good for up to 16384 iterations
+static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, size_t errlen) {
+    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    const uint64_t iters0 = e->h_st->iters;
+    uint64_t remaining = max_iters;
+    const int64_t per = (int64_t)e->nbs * e->cpb;  // layout of the pricing buffer (Xchg, one segment)
+    while (remaining > 0) {
+        SmallArgs a{};
+        a.A_B = e->A_B; a.A_N = e->A_N; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+        a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+        a.kbuf = e->X + 2 * e->nbs;
+        a.rbuf = e->X + 2 * e->nbs + per;
+        a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
+        a.max_iters = remaining < 16384 ? remaining : 16384;
+        a.nch = (int)((e->nN + 63) / 64);
+        a.eps = e->eps;
+        if (e->kind == ELLP_ENGINE_PRIMAL)
+            hipLaunchKernelGGL(k_small<0>, dim3(1), dim3(SMALL_THREADS), e->small_lds, e->stream, a);
+        else
+            hipLaunchKernelGGL(k_small<1>, dim3(1), dim3(SMALL_THREADS), e->small_lds, e->stream, a);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        e->refactors = e->h_st->iters;  // one LU per loop body, as the reference
+        if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+        const uint64_t done = e->h_st->iters - iters0;
+        remaining = done < max_iters ? max_iters - done : 0;
+    }
+    return ELLP_MAXITER;
+}
+
 double ellp_engine_refresh(ellp_engine *e) {
     if (!e) return NAN;
     if (hipSetDevice(e->device) != hipSuccess) return NAN;
+    if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return NAN;
     launch_refresh(e);
     if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess) return NAN;
     if (hipStreamSynchronize(e->stream) != hipSuccess) return NAN;
@@ -2990,6 +3080,9 @@ double ellp_engine_refresh(ellp_engine *e) {
 ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
+    e->w_valid = true;  // about to be
+    e->small = false;
+    e->need_dleave = true;
     launch_refactor(e);
     HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -3009,6 +3102,8 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     ellp_status result = ELLP_MAXITER;
     if (e->nN == 0) {
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
+    } else if (e->small && e->world == 1) {
+        result = run_small(e, max_iters, errbuf, errlen);
     } else {
         uint64_t remaining = max_iters;
         if (e->world != 1) {
@@ -3160,7 +3255,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                 dst[16] = (double)e->refactors;
                 dst[17] = (double)e->resyncs;
                 dst[18] = h.resid;
-                dst[19] = 3.0;
+                dst[19] = e->small ? 0.0 : 3.0;  // 0: whole iterations inside one persistent launch
                 return 20;
             }
             return 14;
@@ -3171,6 +3266,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
         // row-major m x m without the padding
         count = e->m * e->m;
         if (count > cap) return ELLP_ERR_ARG;
+        if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return ELLP_ERR_DEVICE;
         if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
             hipStreamSynchronize(e->stream) != hipSuccess)
             return ELLP_ERR_DEVICE;
@@ -3194,6 +3290,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
 ellp_status ellp_engine_request_maintenance(ellp_engine *e) {
     if (!e) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    if (e->small) return ELLP_OPTIMAL;  // k_small carries no inverse: every iteration starts from a fresh LU
     const int32_t one = 1;
     if (hipMemcpyAsync(&e->st->tiny, &one, sizeof(int32_t), hipMemcpyHostToDevice, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess)
@@ -3204,6 +3301,7 @@ ellp_status ellp_engine_request_maintenance(ellp_engine *e) {
 ellp_status ellp_engine_debug_scale_inverse(ellp_engine *e, double factor) {
     if (!e) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return ELLP_ERR_DEVICE;
     hipLaunchKernelGGL(k_scale_inverse, dim3(512), dim3(256), 0, e->stream, e->W, e->W2, e->st, e->m * e->ld, factor);
     if (hipStreamSynchronize(e->stream) != hipSuccess) return ELLP_ERR_DEVICE;
     e->u_valid = false;
@@ -3213,6 +3311,7 @@ ellp_status ellp_engine_debug_scale_inverse(ellp_engine *e, double factor) {
 double ellp_engine_inverse_residual(ellp_engine *e) {
     if (!e) return NAN;
     if (hipSetDevice(e->device) != hipSuccess) return NAN;
+    if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return NAN;
     hipLaunchKernelGGL(k_inv_residual, dim3((unsigned)e->m), dim3(256), 0, e->stream, e->W, e->W2, e->st, e->A_B,
                        e->m, e->ld, e->resid);
     std::vector<double> h((size_t)e->m);
@@ -3232,6 +3331,10 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
     }
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
+    {
+        const ellp_status si = ensure_inverse(e, errbuf, errlen);  // the stepped loop is the explicit-inverse engine's
+        if (si != ELLP_OPTIMAL) return si;
+    }
     e->rank = rank;
     e->world = world;
     e->nbs = (e->nblocks + world - 1) / world;
@@ -3275,6 +3378,10 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
     }
     HIPCHK(hipSetDevice(e->device));
     if (e->nN == 0) return ELLP_OPTIMAL;
+    if (e->small || !e->w_valid) {
+        const ellp_status si = ensure_inverse(e, errbuf, errlen);
+        if (si != ELLP_OPTIMAL) return si;
+    }
     if (phase == 0) {
         int64_t period = e->refactor_period > 0 ? e->refactor_period : default_period(e);
         if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);

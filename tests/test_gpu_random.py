@@ -110,6 +110,9 @@ def flat(v):
     return _E().FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B, v.N[:v.nN], v.Nb[:v.nN], v.y, v.d)
 
 SEAM_MAX_ITER = [2000]
+# ellp_opts.pipeline for the seam calls: 0 = the engine as a user gets it (m <= 128: the persistent
+# exact kernel of ellp_small.inc), 1 = the explicit-inverse engine with its default maintenance
+SEAM_PIPELINE = [0]
 
 
 def seam(view, which, max_iter=None):
@@ -120,9 +123,16 @@ def seam(view, which, max_iter=None):
     else:
         st_o, it_o, err_o = eo.dual_solve_with_initial(ov, max_iter)
     fp = flat(view)
-    opts = _E().default_opts(max_iter=max_iter)
+    opts = _E().default_opts(max_iter=max_iter, pipeline=SEAM_PIPELINE[0])
     st_g, stats, err_g = (_E().primal_solve_with_initial if which == "primal" else _E().dual_solve_with_initial)(fp, opts)
     return ov, st_o, it_o, fp, st_g, stats, err_o, err_g
+
+
+@pytest.fixture(params=[0, 1], ids=["default-path", "explicit-inverse"])
+def pipeline(request):
+    SEAM_PIPELINE[0] = request.param
+    yield request.param
+    SEAM_PIPELINE[0] = 0
 
 def compare(tag, ov, st_o, it_o, fp, st_g, stats, err_o, err_g, out):
     if st_o != st_g:
@@ -175,8 +185,10 @@ def _campaign(seed0, count, make=None):
     return n, bad
 
 
-def test_random_lps_primal_exact_dual_same_objective():
+def test_random_lps_primal_exact_dual_same_objective(pipeline):
     n, bad = _campaign(1000, 400)
+    if pipeline == 0:  # the exact kernel: every run is the oracle's, pivot for pivot, dual ties included
+        assert not bad, bad[:5]
     assert n["primal"] > 250 and n["dual"] > 250
     hard = [b for b in bad if b[1] != "path"]                       # status or point differs
     assert not hard, hard[:5]
@@ -187,10 +199,12 @@ def test_random_lps_primal_exact_dual_same_objective():
     assert len(dual_paths) <= 0.03 * n["dual"], (len(dual_paths), n["dual"])
 
 
-def test_random_feasible_bounded_lps_both_phases():
+def test_random_feasible_bounded_lps_both_phases(pipeline):
     """The same checks on LPs that are feasible and bounded by construction, so that phase 2 runs too
     (most purely random LPs end infeasible or unbounded in phase 1)."""
     n, bad = _campaign(7000, 300, feasible_fixture)
+    if pipeline == 0:  # the exact kernel shares even the reference's rounding-fragile panics (quirk Q1)
+        assert not bad, bad[:5]
     assert n["primal"] > 250 and n["dual"] > 200
     # Quirk Q1 (primal…:359 + assert :402) makes the reference itself rounding-fragile on box-bounded
     # LPs: a TwoSided basic that sits ON its lower bound up to the last bit gives lambda_i = (lb - x)/d
@@ -243,7 +257,7 @@ def test_random_lps_end_to_end_through_the_host_mirror():
     assert n_fragile <= 15, n_fragile
 
 
-def test_random_wide_lps_first_400_pivots():
+def test_random_wide_lps_first_400_pivots(pipeline):
     """Few rows, thousands of columns of every bound kind: several columns per pricing block, bound
     flips, Fixed and TwoSided entering variables, reduced costs up to 1e7 (near-singular bases).  The
     reference's rules are not sound on such LPs (quirk Q1 leaves nonbasic variables strictly inside
@@ -304,6 +318,29 @@ NETLIB_ORDERS = 60
 
 
 @pytest.mark.parametrize("name", ["afiro", "adlittle", "blend"])
+def test_netlib_in_random_orders_explicit_inverse(name, monkeypatch):
+    """The explicit-inverse engine (pipeline 1) on 6 orders per problem, as in round 1.  It is NOT
+    what small LPs run on by default any more: ADLITTLE's dual passes through bases of condition
+    1e7-1e9, where an explicit inverse is only good to 1e-7 however it is maintained, and about 2 % of
+    its variable orders end wrongly (tests/golden/netlib_orders.json)."""
+    import os
+    import zlib
+    from helpers import GOLDEN, known_answers, read_mps
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == name)
+    base = read_mps(os.path.join(GOLDEN, ka["file"]))
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    SEAM_PIPELINE[0] = 1
+    try:
+        bad = []
+        for trial in range(6):
+            netlib_order_case(base, ka, _permuted(base, rng), trial, bad)
+    finally:
+        SEAM_PIPELINE[0] = 0
+    assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
+    assert len(bad) <= 3, len(bad)
+
+
+@pytest.mark.parametrize("name", ["afiro", "adlittle", "blend"])
 def test_netlib_in_random_orders(name):
     """Real, sparse, degenerate LPs in 60 random variable/constraint orders each (the size of the
     campaign that found the round-1 dual failures; the reference iterates HashMaps, so every order
@@ -319,9 +356,7 @@ def test_netlib_in_random_orders(name):
     for trial in range(NETLIB_ORDERS):
         fx = _permuted(base, rng)
         netlib_order_case(base, ka, fx, trial, bad)
-    # pivot for pivot except where a degenerate tie falls the other way (same objective then)
-    assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
-    assert len(bad) <= 0.25 * 2 * NETLIB_ORDERS, len(bad)  # of 2 primal phase runs per order
+    assert not bad, bad[:5]  # the exact kernel: the oracle's path in every order
 
 
 def _regression_orders():
@@ -352,4 +387,4 @@ def test_netlib_regression_orders(case):
           "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
     bad = []
     netlib_order_case(base, ka, fx, case["tag"], bad)
-    assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
+    assert not bad, bad

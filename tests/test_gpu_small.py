@@ -1,0 +1,170 @@
+"""The persistent exact kernel for small LPs (ellp_amd/csrc/engine/ellp_small.inc, m <= 128, the
+default path at that size): it performs the oracle's floating-point operations in the oracle's order,
+so everything must be EQUAL — iteration counts, index sets, and the bits of x, y and d — on the 25
+known answers, the netlib fixtures, random LPs of every bound kind, for the primal and the dual loop,
+including error outcomes."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, known_answers, read_mps
+from oracle import ellp_oracle as eo
+
+pytestmark = pytest.mark.gpu
+KA = known_answers()
+
+
+def _E():
+    from ellp_amd import _engine as E
+    return E
+
+
+def flat(v):
+    return _E().FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B, v.N[:v.nN], v.Nb[:v.nN], v.y, v.d)
+
+
+def both(view, which, max_iter):
+    E = _E()
+    ov = view.copy()
+    fn_o = eo.primal_solve_with_initial if which == "primal" else eo.dual_solve_with_initial
+    st_o, it_o, err_o = fn_o(ov, max_iter)
+    fp = flat(view)
+    fn_g = E.primal_solve_with_initial if which == "primal" else E.dual_solve_with_initial
+    st_g, stats, err_g = fn_g(fp, E.default_opts(max_iter=max_iter, pipeline=3))
+    return ov, st_o, it_o, err_o, fp, st_g, stats, err_g
+
+
+def assert_identical(tag, ov, st_o, it_o, err_o, fp, st_g, stats, err_g, which):
+    assert st_g == st_o, (tag, st_g, st_o, err_g, err_o)
+    assert stats.iters == it_o, (tag, stats.iters, it_o)
+    if st_o < 0:
+        return
+    np.testing.assert_array_equal(fp.B, ov.B, err_msg=str(tag))
+    np.testing.assert_array_equal(fp.N[:fp.nN], ov.N[:ov.nN], err_msg=str(tag))
+    np.testing.assert_array_equal(fp.Nb[:fp.nN], ov.Nb[:ov.nN], err_msg=str(tag))
+    assert fp.x.tobytes() == np.asarray(ov.x, dtype=np.float64).tobytes(), (tag, np.abs(fp.x - ov.x).max())
+    if which == "dual":
+        assert fp.y.tobytes() == np.asarray(ov.y, dtype=np.float64).tobytes(), (tag, np.abs(fp.y - ov.y).max())
+        assert fp.d.tobytes() == np.asarray(ov.d, dtype=np.float64).tobytes(), (tag, np.abs(fp.d - ov.d).max())
+
+
+def two_phases(fx, which, max_iter=5000):
+    """phase 1 and phase 2 at the seam, each from the oracle's arrays; returns the number of phases run"""
+    prob = eo.Problem.from_fixture(fx)
+    if which == "primal":
+        p1, err = eo.primal_phase1(prob)
+    else:
+        p1, err = eo.dual_phase1(prob)
+    if p1 is None or err:
+        return 0
+    v1 = p1.view()
+    if v1.m == 0 or (which == "primal" and v1.nN == 0) or v1.m > 128:
+        return 0
+    r = both(v1, which, max_iter)
+    assert_identical((which, 1), *r, which)
+    ov = r[0]
+    if r[1] != eo.OPTIMAL:
+        return 1
+    if which == "primal":
+        if not abs(ov.obj()) < 1e-10:
+            return 1
+        p1.store_point(ov)
+        v2 = eo.primal_phase2(p1).view()
+    else:
+        p1.store_point(ov)
+        if not (p1.dual_obj() > -1e-10):
+            return 1
+        p2, err2 = eo.dual_phase2(p1)
+        if p2 is None or err2:
+            return 1
+        v2 = p2.view()
+        if v2.m == 0:
+            return 1
+    r2 = both(v2, which, max_iter)
+    assert_identical((which, 2), *r2, which)
+    return 2
+
+
+@pytest.mark.parametrize("which", ["primal", "dual"])
+@pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
+def test_known_answers_bit_for_bit(fx, which):
+    two_phases(fx, which)
+
+
+@pytest.mark.parametrize("which", ["primal", "dual"])
+@pytest.mark.parametrize("fx", KA["netlib"], ids=[p["name"] for p in KA["netlib"]])
+def test_netlib_bit_for_bit(fx, which):
+    assert two_phases(read_mps(os.path.join(GOLDEN, fx["file"])), which, 20000) == 2
+
+
+def test_random_lps_bit_for_bit():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_random import feasible_fixture, random_fixture
+    ran = 0
+    for s in range(20000, 20150):
+        ran += two_phases(random_fixture(np.random.default_rng(s)), "primal")
+        ran += two_phases(random_fixture(np.random.default_rng(s)), "dual")
+    for s in range(21000, 21100):
+        ran += two_phases(feasible_fixture(np.random.default_rng(s)), "primal")
+        ran += two_phases(feasible_fixture(np.random.default_rng(s)), "dual")
+    assert ran > 400
+
+
+def test_wide_lp_bit_for_bit():
+    """thousands of columns (many pricing chunks), every bound kind, bound flips; 600 pivots per phase"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_random import wide_fixture
+    for s in (300, 305):
+        assert two_phases(wide_fixture(np.random.default_rng(s)), "primal", 600) >= 1
+        assert two_phases(wide_fixture(np.random.default_rng(s)), "dual", 600) >= 1
+
+
+def test_largest_size_and_slices():
+    """m = 128 (the LU fills 128 KB of LDS), run in slices through the resident API: the slices must
+    compose to the oracle's run"""
+    E = _E()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(11, 128, 300)
+
+    class V:
+        pass
+    ov = V()
+    for k, val in f.items():
+        setattr(ov, k, val.copy() if hasattr(val, "copy") else val)
+    ov.nB, ov.nN = len(f["B"]), len(f["N"])
+    st_o, it_o, _ = eo.primal_solve_with_initial(ov, 700)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+    assert eng.counters()["launches_per_iteration"] == 0
+    total = 0
+    for k in (1, 2, 97, 600):
+        st, stats, msg = eng.run(k)
+        total += k
+        assert stats.iters == min(total, it_o), msg
+    eng.read_point()
+    eng.close()
+    assert st == st_o
+    np.testing.assert_array_equal(fp.B, ov.B)
+    assert fp.x.tobytes() == ov.x.tobytes()
+
+
+def test_switching_to_the_explicit_inverse_mid_run():
+    """An engine that has been running the exact kernel can be handed to the explicit-inverse engine
+    (anything that needs B^-1: a refresh, the stepped/sharded API): B^-1 is built from the current basis."""
+    E = _E()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(20260301, 50, 120)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
+                       f["B"], f["N"], f["Nb"])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+    eng.run(60)
+    assert eng.inverse_residual() < 1e-12   # builds B^-1 and leaves the small path
+    assert eng.counters()["launches_per_iteration"] == 3
+    st, stats, msg = eng.run(1 << 40)
+    eng.read_point()
+    eng.close()
+    assert st == E.OPTIMAL and abs(fp.obj()) < 1e-9, msg
