@@ -72,7 +72,7 @@ def _worker(rank, world, port, q):
             cases.append((f"random-primal-{seed}", E.ENGINE_PRIMAL, lambda seed=seed: _random_flat(seed, "primal"), 150))
             cases.append((f"random-dual-{seed}", E.ENGINE_DUAL, lambda seed=seed: _random_flat(seed, "dual"), 150))
         for name, kind, make, cap in cases:
-            opts = E.default_opts(max_iter=None, device=0)
+            opts = E.default_opts(max_iter=None, device=0, pipeline=1)  # the explicit-inverse engine on both sides
             ref_fp = make()
             ref = E.Engine(kind, ref_fp, opts)
             st_ref, stats_ref, _ = ref.run(cap)
@@ -125,10 +125,11 @@ def test_sharded_engine_takes_the_same_pivots_world2():
 
 
 def test_stepped_api_world1_matches_run():
-    """ShardedEngine with a single rank (no process group) == Engine.run."""
+    """ShardedEngine with a single rank (no process group) == Engine.run of the same (explicit-inverse)
+    engine; pipeline 1: at this size the default path of run() would be the exact small-LP kernel."""
     from ellp_amd import _engine as E
     from ellp_amd.dist import ShardedEngine
-    opts = E.default_opts(max_iter=None)
+    opts = E.default_opts(max_iter=None, pipeline=1)
     a = _flat(7, 40, 90)
     e1 = E.Engine(E.ENGINE_PRIMAL, a, opts)
     st1, s1, _ = e1.run(100000)
@@ -153,7 +154,7 @@ def test_library_loop_with_direct_rccl_world1():
     from ellp_amd import _engine as E
     from ellp_amd.dist import ShardedEngine
     for kind, make in ((E.ENGINE_PRIMAL, lambda: _flat(20260301, 200, 500)), (E.ENGINE_DUAL, _dual_flat)):
-        opts = E.default_opts(max_iter=None, device=0)
+        opts = E.default_opts(max_iter=None, device=0, pipeline=1)
         ref_fp = make()
         ref = E.Engine(kind, ref_fp, opts)
         st_ref, stats_ref, _ = ref.run(3000)

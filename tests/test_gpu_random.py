@@ -288,28 +288,44 @@ def _permuted(fx, rng):
             "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
 
 
-def netlib_order_case(base, ka, fx, trial, bad):
-    """One variable/constraint order of a netlib LP: primal phase by phase pivot for pivot against the
-    oracle (a degenerate tie may fall the other way: same objective then), dual phase by phase to the
-    same status and objective; both must end at the pinned optimum (tests/problems/mod.rs:658-672).
-    Returns the number of primal phase runs that took another tie path."""
+def netlib_order_case(base, ka, fx, trial, bad, ref_errors=None):
+    """One variable/constraint order of a netlib LP: primal and dual, phase by phase at the seam,
+    oracle against engine (compare(): status, pivots, point); both must end at the pinned optimum
+    (tests/problems/mod.rs:658-672).  The reference itself does not survive every order: its primal
+    guard is ABSOLUTE (any |U_ii| < 1e-10 is Err("A_B is not invertible"), primal…:175-179) and BLEND
+    has coefficients of 1e-4, so about one order in a hundred ends in that error in the oracle — and
+    must end in the same error, at the same iteration, in the engine.  Such orders are appended to
+    `ref_errors` (or fail the case when that is None)."""
     prob = eo.Problem.from_fixture(fx)
     p1, err = eo.primal_phase1(prob)
     r = seam(p1.view(), "primal", 5000)
     compare((trial, "primal1"), *r, bad)
-    assert r[1] == r[4] == eo.OPTIMAL and abs(r[0].obj()) < 1e-10 and abs(r[3].obj()) < 1e-9, (trial, r[1], r[4], r[7])
-    p1.store_point(r[0])
-    r2 = seam(eo.primal_phase2(p1).view(), "primal", 5000)
-    compare((trial, "primal2"), *r2, bad)
-    assert r2[1] == r2[4] == eo.OPTIMAL and abs(r2[3].obj() / ka["obj"] - 1.0) < 1e-6, (trial, r2[1], r2[4], r2[7])
-    # dual, at the seam: same status and objective
+    primal_ok = True
+    if r[1] < 0 and ref_errors is not None:
+        assert r[4] == r[1] and r[5].iters == r[2], (trial, "primal1", r[1], r[4], r[2], r[5].iters, r[7])
+        ref_errors.append((trial, "primal1", r[1], r[6]))
+        primal_ok = False
+    else:
+        assert r[1] == r[4] == eo.OPTIMAL and abs(r[0].obj()) < 1e-10 and abs(r[3].obj()) < 1e-9, (trial, r[1], r[4], r[7])
+    if primal_ok:
+        p1.store_point(r[0])
+        r2 = seam(eo.primal_phase2(p1).view(), "primal", 5000)
+        compare((trial, "primal2"), *r2, bad)
+        if r2[1] < 0 and ref_errors is not None:
+            assert r2[4] == r2[1] and r2[5].iters == r2[2], (trial, "primal2", r2[1], r2[4], r2[7])
+            ref_errors.append((trial, "primal2", r2[1], r2[6]))
+        else:
+            assert r2[1] == r2[4] == eo.OPTIMAL and abs(r2[3].obj() / ka["obj"] - 1.0) < 1e-6, (trial, r2[1], r2[4], r2[7])
+    # dual, at the seam
     d1, err = eo.dual_phase1(prob)
     rd = seam(d1.view(), "dual", 20000)
+    compare((trial, "dual1"), *rd, bad)
     assert rd[1] == rd[4] == eo.OPTIMAL, (trial, "dual1", rd[1], rd[4], rd[7])
     d1.store_point(rd[0])
     d2, err2 = eo.dual_phase2(d1)
     assert d2 is not None and not err2
     rd2 = seam(d2.view(), "dual", 20000)
+    compare((trial, "dual2"), *rd2, bad)
     assert rd2[1] == rd2[4] == eo.OPTIMAL, (trial, "dual2", rd2[1], rd2[4], rd2[7])
     assert abs(rd2[3].obj() / ka["obj"] - 1.0) < 1e-6 and abs(rd2[0].obj() / ka["obj"] - 1.0) < 1e-6, (trial, rd2[3].obj())
 
@@ -336,8 +352,9 @@ def test_netlib_in_random_orders_explicit_inverse(name, monkeypatch):
             netlib_order_case(base, ka, _permuted(base, rng), trial, bad)
     finally:
         SEAM_PIPELINE[0] = 0
+    # pivot for pivot except where a degenerate tie falls the other way (same objective then)
     assert all(b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])) for b in bad), bad
-    assert len(bad) <= 3, len(bad)
+    assert len([b for b in bad if b[0][1].startswith("primal")]) <= 3, bad
 
 
 @pytest.mark.parametrize("name", ["afiro", "adlittle", "blend"])
@@ -352,11 +369,12 @@ def test_netlib_in_random_orders(name):
     base = read_mps(os.path.join(GOLDEN, ka["file"]))
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    bad = []
+    bad, ref_errors = [], []
     for trial in range(NETLIB_ORDERS):
         fx = _permuted(base, rng)
-        netlib_order_case(base, ka, fx, trial, bad)
-    assert not bad, bad[:5]  # the exact kernel: the oracle's path in every order
+        netlib_order_case(base, ka, fx, trial, bad, ref_errors)
+    assert not bad, bad[:5]  # the exact kernel: the oracle's path in every order, dual ties included
+    assert len(ref_errors) <= 2, ref_errors  # orders the reference's own absolute guard rejects
 
 
 def _regression_orders():

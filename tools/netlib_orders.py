@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/netlib_orders.py [orders_per_problem] [seed] — the campaign behind
+"""tools/netlib_orders.py [orders_per_problem] [seed] [pipeline] — the campaign behind
 tests/test_gpu_random.py::test_netlib_in_random_orders, without stopping at the first failure: netlib
 AFIRO / ADLITTLE / BLEND in random variable and constraint orders through the dual and primal loops,
 oracle (CPU) against engine (GPU).  Every order on which the two end differently (status or objective)
@@ -37,6 +37,9 @@ def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     failures, total = [], 0
+    n_ref_errors = n_paths = 0
+    if len(sys.argv) > 3:
+        T.SEAM_PIPELINE[0] = int(sys.argv[3])
     for name in ("afiro", "adlittle", "blend"):
         ka = next(p for p in known_answers()["netlib"] if p["name"] == name)
         base = read_mps(os.path.join(GOLDEN, ka["file"]))
@@ -44,10 +47,12 @@ def main():
         for trial in range(count):
             fx, perm, rperm = permuted(base, rng)
             total += 1
-            bad = []
+            bad, ref_errors = [], []
             try:
-                T.netlib_order_case(base, ka, fx, trial, bad)
+                T.netlib_order_case(base, ka, fx, trial, bad, ref_errors)
+                n_ref_errors += len(ref_errors)
                 hard = [b for b in bad if not (b[1] == "path" and b[4] < 1e-8 * (1 + abs(ka["obj"])))]
+                n_paths += len(bad) - len(hard)
                 if hard:
                     raise AssertionError(str(hard[:2]))
             except AssertionError as e:
@@ -59,7 +64,8 @@ def main():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(out, "w") as f:
         json.dump({"orders_per_problem": count, "seed": seed, "total": total, "failures": failures}, f)
-    print(json.dumps({"total": total, "failed": len(failures)}))
+    print(json.dumps({"total": total, "failed": len(failures), "orders_the_reference_itself_rejects": n_ref_errors,
+                      "other_tie_paths": n_paths, "pipeline": T.SEAM_PIPELINE[0]}))
 
 
 if __name__ == "__main__":
