@@ -89,6 +89,17 @@ struct DevState {
     // ---- results
     double lambda, obj;
     double drift;  // last k_drift_reduce: max|A_B (B^-1 a_q) - a_q| / max|a_q|
+    // ---- two-launch pipeline (ellp_lagged.inc)
+    int32_t fin;        // k_ftran_eta: final status + 1 (0: none); the next kernel's leader makes it the status
+    int32_t tiny_p;     // k_price2's bookkeeping: tiny pivot; k_ftran_eta relays it into `tiny`
+    int32_t pe_valid;   // k_price2 leader: k_ftran_eta has the eta update of the pivot just committed to apply
+    int32_t f_src;      // k_price2 leader: the B^-1 buffer k_ftran_eta reads
+    int64_t pe_r;
+    double pe_d_r, pe_alpha_r;
+    int32_t usel, usel_next;  // which of the two u buffers is current / becomes current after k_ftran_eta
+    int32_t mv_pending, mv_pad;
+    int64_t mv_r;       // deferred half of the column move: A_B[:, mv_r] <- aq_save, c_B[mv_r] <- cq_save
+    double cq_save;
     double resid;  // last Newton-Schulz refresh: max|I - A_B W| before the step (k_resid_reduce)
     int32_t need_rebuild;  // that residual was too large for a Newton-Schulz step: the host must rebuild
     int32_t pad_nr;
@@ -1111,7 +1122,7 @@ struct Update2Args {
     const int32_t *bidx;
     const uint8_t *dpos;
     Xchg xc;              // dual: alpha_j = xc.r(j)
-    double *u, *A_N, *A_B, *c_B, *c_N, *x, *y, *dd;
+    double *u, *u_alt, *A_N, *A_B, *c_B, *c_N, *x, *y, *dd;  // u_alt: second u buffer (DevState::usel, two-launch pipeline)
     const double *lb, *ub;
     const uint8_t *kind;
     int64_t *B_index, *N_index;
@@ -1135,6 +1146,10 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     __shared__ long long s_tmp[4];
     DevState *st = a.st;
     if (st->status != ST_RUNNING) return;
+    if (MODE == 0 && st->fin) {  // closing kernel of the two-launch pipeline: k_ftran_eta found the end of the solve
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->status = st->fin - 1;
+        return;
+    }
     STAMP(2, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m = a.m;
@@ -1359,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             if (a.update_u) {
                 const double cf = st->s_rq / alpha_r;
                 const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
-                double2 *u2 = reinterpret_cast<double2 *>(a.u);
+                double2 *u2 = reinterpret_cast<double2 *>(st->usel ? a.u_alt : a.u);
                 for (int64_t t = tid; t < (a.ld >> 1); t += 256) {
                     const double2 p = rho2[t];
                     double2 w = u2[t];
@@ -1507,7 +1522,7 @@ __global__ __launch_bounds__(256) void k_dleave(DLeaveArgs a) {
 // between u is carried by the O(m) update in k_update2.
 struct BtranArgs {
     const double *W0, *W1, *c_B;
-    double *upart, *u;
+    double *upart, *u, *u_alt;
     DevState *st;
     int64_t m, ld;
     int rows_per_tile, ntiles;
@@ -1547,7 +1562,7 @@ __global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
         for (int k = 0; k < 8; ++k) s += v[k];
     }
     for (; t < a.ntiles; ++t) s += a.upart[(int64_t)t * a.ld + j];
-    a.u[j] = s;
+    (a.st->usel ? a.u_alt : a.u)[j] = s;
 }
 
 // ------------------------------------------------------------------ drift monitor of B^-1
@@ -2107,6 +2122,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
     }
 }
 
+#include "ellp_lagged.inc"
 #include "ellp_small.inc"
 
 }  // namespace
@@ -2137,6 +2153,10 @@ struct ellp_engine {
     uint64_t resyncs = 0;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
+    double *aq_save = nullptr, *bmin = nullptr;  // two-launch pipeline: parked entering column, row-block minima of lambda
+    bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
+    bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
+    size_t price2_lds = 0;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
     uint64_t refreshes = 0, maint_requests = 0;
     double last_residual = 0.0;
@@ -2355,7 +2375,7 @@ template <int MODE>
 void launch_update2(ellp_engine *e, int update_u) {
     Update2Args a{};
     a.W0 = e->W; a.W1 = e->W2; a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
-    a.u = e->u; a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+    a.u = e->u; a.u_alt = e->u + e->ld; a.A_N = e->A_N; a.A_B = e->A_B; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd2_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
@@ -2371,7 +2391,7 @@ void launch_update2(ellp_engine *e, int update_u) {
 }
 
 void launch_btran(ellp_engine *e) {
-    BtranArgs a{e->W, e->W2, e->c_B, e->upart, e->u, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
+    BtranArgs a{e->W, e->W2, e->c_B, e->upart, e->u, e->u + e->ld, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
     const int64_t half = e->ld >> 1;
     dim3 g((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles);
     hipLaunchKernelGGL(k_btran_part, g, dim3(256), 0, e->stream, a);
@@ -2470,6 +2490,10 @@ void launch_resync(ellp_engine *e) {
 // such a request) is kept for diagnostics: resynchronising only then was tried and is worse (netlib
 // ADLITTLE / BLEND in 60 variable orders, dual: 4 wrong outcomes instead of 1).
 void maintain_inverse(ellp_engine *e, bool reactive = false, bool rebuild = false) {
+    // two-launch pipeline: an open iteration (priced, FTRAN done, ratio test not folded) was decided with
+    // the inverse that is about to be replaced — drop it; the next k_price2 starts afresh (use_pend = 0) and
+    // the iteration is priced again from the maintained inverse.  Its eta-update half is already in B^-1.
+    e->lag_open = false;
     if (rebuild) launch_refactor(e);
     else launch_refresh(e);
     const char *mode = getenv("ELLP_RESYNC");  // diagnostics: "0" never, "1" only on reactive maintenance
@@ -2532,7 +2556,104 @@ void launch_drift_check(ellp_engine *e) {
     hipLaunchKernelGGL(k_drift_reduce, dim3(1), dim3(1024), 0, e->stream, a);
 }
 
+// ---- two-launch pipeline (ellp_lagged.inc) -------------------------------------------------------
+void launch_price2(ellp_engine *e, int use_pend) {
+    Price2Args a{};
+    a.p.A_N = e->A_N; a.p.W0 = e->W; a.p.W1 = e->W2; a.p.u = nullptr; a.p.c_N = e->c_N; a.p.Nb = e->Nb;
+    a.p.N_index = e->N_index; a.p.dd = nullptr; a.p.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.p.st = e->st;
+    a.p.ld = e->ld; a.p.nN = e->nN; a.p.cpb = e->cpb; a.p.block0 = e->rank * e->nbs; a.p.eps = e->eps;
+    a.u0 = e->u; a.u1 = e->u + e->ld; a.W0 = e->W; a.W1 = e->W2;
+    a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bidx = e->bidx; a.dpos = e->dpos;
+    a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
+    a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+    a.m = e->m; a.rpb = e->upd2_rows; a.use_pend = use_pend; a.ill_tol = e->ill_tol;
+    int mine = e->nblocks - a.p.block0;
+    if (mine > e->nbs) mine = e->nbs;
+    if (mine < 0) mine = 0;
+    const dim3 g(mine + P2_BOOK), b(256);
+    const size_t lds = e->price2_lds;
+    if (e->price_wave) {
+        hipLaunchKernelGGL(k_price2_wave, g, b, lds + sizeof(double) * (size_t)e->ld, e->stream, a);
+        return;
+    }
+    if (e->price_nt) {
+        switch (e->priceT) {
+        case 1: hipLaunchKernelGGL((k_price2<1, true>), g, b, lds, e->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_price2<2, true>), g, b, lds, e->stream, a); break;
+        case 4: hipLaunchKernelGGL((k_price2<4, true>), g, b, lds, e->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_price2<8, true>), g, b, lds, e->stream, a); break;
+        default: hipLaunchKernelGGL((k_price2<16, true>), g, b, lds, e->stream, a); break;
+        }
+    } else {
+        switch (e->priceT) {
+        case 1: hipLaunchKernelGGL((k_price2<1, false>), g, b, lds, e->stream, a); break;
+        case 2: hipLaunchKernelGGL((k_price2<2, false>), g, b, lds, e->stream, a); break;
+        case 4: hipLaunchKernelGGL((k_price2<4, false>), g, b, lds, e->stream, a); break;
+        case 8: hipLaunchKernelGGL((k_price2<8, false>), g, b, lds, e->stream, a); break;
+        default: hipLaunchKernelGGL((k_price2<16, false>), g, b, lds, e->stream, a); break;
+        }
+    }
+}
+
+void launch_ftran_eta(ellp_engine *e) {
+    FtranEtaArgs a{};
+    a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
+    a.N_index = e->N_index; a.B_index = e->B_index; a.Nb = e->Nb; a.kind = e->kindv;
+    a.x = e->x; a.lb = e->lb; a.ub = e->ub; a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bidx = e->bidx; a.dpos = e->dpos;
+    a.A_B = e->A_B; a.c_B = e->c_B; a.aq_save = e->aq_save; a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
+    a.nblocks = e->nblocks; a.cpb = e->cpb; a.rows_per_block = e->upd2_rows; a.eps = e->eps;
+    const dim3 g(e->upd2_blocks + 1), b(256);
+    const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
+    if (nr <= 1) hipLaunchKernelGGL((k_ftran_eta<1>), g, b, e->ftran_lds, e->stream, a);
+    else if (nr <= 2) hipLaunchKernelGGL((k_ftran_eta<2>), g, b, e->ftran_lds, e->stream, a);
+    else if (nr <= 4) hipLaunchKernelGGL((k_ftran_eta<4>), g, b, e->ftran_lds, e->stream, a);
+    else if (nr <= 8) hipLaunchKernelGGL((k_ftran_eta<8>), g, b, e->ftran_lds, e->stream, a);
+    else hipLaunchKernelGGL((k_ftran_eta<0>), g, b, e->ftran_lds, e->stream, a);
+}
+
+// iteration k of the two-launch pipeline: P_k folds and books iteration k-1 (if one is open), prices k;
+// F_k applies the eta of k-1 and forms d_k.  Iteration k itself stays open until the next P or the flush.
+void launch_primal_iteration_lagged(ellp_engine *e) {
+    const bool full_btran = !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;
+    if (full_btran) {
+        // u = B^-T c_B from the materialised inverse: W and c_B both stand at "all pivots but the open one",
+        // exactly the u_{k-1} that P_k advances by the open pivot's rank-1 term
+        Prof p(e, ELLP_K_BTRAN);
+        launch_btran(e);
+        e->since_btran = 0;
+        e->u_valid = true;
+    }
+    {
+        Prof p(e, ELLP_K_PRICE);
+        launch_price2(e, e->lag_open ? 1 : 0);
+    }
+    {
+        Prof p(e, ELLP_K_FTRAN);
+        launch_ftran_eta(e);
+    }
+    launch_drift_check(e);
+    e->lag_open = true;
+    e->since_btran += 1;
+    e->since_refactor += 1;
+    e->enqueued += 1;
+}
+
+// closing kernel of a slice: k_update2 folds the open iteration's ratio test, applies its eta update and
+// does its bookkeeping (the three-launch path's third kernel, unchanged)
+void launch_flush(ellp_engine *e) {
+    if (!e->lag_open) return;
+    {
+        Prof p(e, ELLP_K_UPDATE);
+        launch_update2<0>(e, 1);
+    }
+    e->lag_open = false;
+}
+
 void launch_primal_iteration(ellp_engine *e) {
+    if (e->lagged) {
+        launch_primal_iteration_lagged(e);
+        return;
+    }
     const bool full_btran = (e->opts.btran_mode == 1) || !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;
     if (full_btran) {
         Prof p(e, ELLP_K_BTRAN);
@@ -2848,7 +2969,9 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->W2, (size_t)(m * ld)));
     ECHK(dmalloc(e, &e->c_B, (size_t)m));
     ECHK(dmalloc(e, &e->c_N, (size_t)nNa));
-    ECHK(dmalloc(e, &e->u, (size_t)ld));
+    ECHK(dmalloc(e, &e->u, (size_t)(2 * ld)));  // two buffers (DevState::usel): the two-launch pipeline reads one, writes the other
+    ECHK(dmalloc(e, &e->aq_save, (size_t)ld));
+    ECHK(dmalloc(e, &e->bmin, (size_t)m));
     e->nbs = e->nblocks;
     e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     ECHK(dmalloc(e, &e->X, (size_t)e->seg));
@@ -2882,7 +3005,8 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         ECHK(dmalloc(e, &e->y, (size_t)ld));
         ECHK(dmalloc(e, &e->dd, (size_t)n_c));
     }
-    ECHK(hipMemsetAsync(e->u, 0, sizeof(double) * (size_t)ld, e->stream));
+    ECHK(hipMemsetAsync(e->u, 0, sizeof(double) * (size_t)(2 * ld), e->stream));
+    ECHK(hipMemsetAsync(e->aq_save, 0, sizeof(double) * (size_t)ld, e->stream));
     ECHK(hipMemsetAsync(e->d, 0, sizeof(double) * (size_t)ld, e->stream));
 
     // upload (A goes through a temporary full copy, then columns are gathered on the device)
@@ -2984,6 +3108,14 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
                 e->small = false;  // the large engine handles it
             }
         }
+    }
+    // two launches per primal iteration from m = 1024 (ellp_lagged.inc), or on request
+    {
+        const int pl = e->opts.pipeline;
+        e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 &&
+                    (pl == 2 || (pl == 0 && m >= 1024));
+        if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
+        e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
     }
     // initial B^-1 (k_small keeps none: its LU is redone every iteration, with the reference's guard)
     if (e->small) e->w_valid = false;
@@ -3159,11 +3291,12 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                     if (wait_on >= 0) {
                         HIPCHK(hipEventSynchronize(e->look_ev[wait_on]));
                         pending[wait_on] = false;
-                        if (e->h_look[wait_on].status != ST_RUNNING || e->h_look[wait_on].tiny) stop = true;
+                        if (e->h_look[wait_on].status != ST_RUNNING || e->h_look[wait_on].tiny || e->h_look[wait_on].fin) stop = true;
                     }
                     if (to_launch == 0 && !pending[0] && !pending[1]) break;
                     slot ^= 1;
                 }
+                launch_flush(e);  // two-launch pipeline: fold and book the iteration that is still open
                 HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
                 HIPCHK(hipStreamSynchronize(e->stream));
                 HIPCHK(hipGetLastError());
@@ -3181,6 +3314,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
                 else launch_dual_iteration(e);
             }
+            launch_flush(e);
             HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             HIPCHK(hipGetLastError());
@@ -3224,7 +3358,13 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
     const double *src = nullptr;
     int64_t count = 0;
     switch (what) {
-    case ELLP_TAP_U: src = e->u; count = e->m; break;
+    case ELLP_TAP_U:
+        if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess)
+            return ELLP_ERR_DEVICE;
+        src = e->u + (e->h_st->usel ? e->ld : 0);
+        count = e->m;
+        break;
     case ELLP_TAP_R:
     case ELLP_TAP_ALPHA:
         if (e->world != 1) return ELLP_ERR_ARG;
@@ -3255,7 +3395,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                 dst[16] = (double)e->refactors;
                 dst[17] = (double)e->resyncs;
                 dst[18] = h.resid;
-                dst[19] = e->small ? 0.0 : 3.0;  // 0: whole iterations inside one persistent launch
+                dst[19] = e->small ? 0.0 : (e->lagged ? 2.0 : 3.0);  // 0: whole iterations inside one persistent launch
                 return 20;
             }
             return 14;
@@ -3334,6 +3474,13 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
     {
         const ellp_status si = ensure_inverse(e, errbuf, errlen);  // the stepped loop is the explicit-inverse engine's
         if (si != ELLP_OPTIMAL) return si;
+    }
+    if (e->lagged) {  // the stepped loop drives the three-launch kernels, which use u buffer 0
+        e->lagged = false;
+        e->lag_open = false;
+        const int32_t zero = 0;
+        HIPCHK(hipMemcpy(&e->st->usel, &zero, sizeof(int32_t), hipMemcpyHostToDevice));
+        e->u_valid = false;
     }
     e->rank = rank;
     e->world = world;
@@ -3490,6 +3637,11 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     ns.status = ST_RUNNING;
     ns.nan_flag = 0;
     ns.tiny = 0;
+    ns.tiny_p = 0;
+    ns.fin = 0;
+    ns.pe_valid = 0;
+    ns.mv_pending = 0;
+    ns.need_rebuild = 0;
     ns.panic_code = 0;
     ns.iters = ns.pivots = ns.flips = 0;
     ns.lambda = 0.0;

@@ -96,7 +96,7 @@ def test_primal_known_answers(fx):
 
 
 @pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
-@pytest.mark.parametrize("pipeline", [0, 1], ids=["default-path", "explicit-inverse"])
+@pytest.mark.parametrize("pipeline", [0, 1, 2], ids=["default-path", "explicit-inverse", "two-launch"])
 def test_primal_known_answers_default_maintenance(fx, pipeline):
     """The same 25 fixtures, pivot for pivot, on the engine exactly as a user gets it (pipeline 0: at
     this size the persistent exact kernel), and on the explicit-inverse engine with its DEFAULT
@@ -394,3 +394,46 @@ def test_primal_tall_and_square_synthetic_window(m, n, W):
     np.testing.assert_array_equal(fp.N, ov.N)
     np.testing.assert_array_equal(fp.Nb, ov.Nb)
     np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("m,n", [(20, 50), (50, 120), (100, 250), (300, 700)])
+def test_two_launch_pipeline_takes_the_same_pivots(m, n):
+    """ellp_opts.pipeline = 2 (eta update fused with the next FTRAN, ratio fold in the pricing prologue)
+    against pipeline = 1 (three launches): the same arithmetic except for the summation order of the
+    FTRAN dot products, so on these well-conditioned LPs the same pivots, iteration for iteration,
+    through slices of every length (the closing kernel of a slice is the three-launch update), both
+    phases, to the oracle's optimum."""
+    E = _engine()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(20260301, m, n)
+
+    def solve(pipeline, slices):
+        fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                           f["x"], f["B"], f["N"], f["Nb"])
+        eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, pipeline=pipeline))
+        assert eng.counters()["launches_per_iteration"] == (3 if pipeline == 1 else 2)
+        trace = []
+        st = E.MAXITER
+        k = 0
+        while st == E.MAXITER:
+            st, stats, msg = eng.run(slices[k % len(slices)])
+            k += 1
+            eng.read_point()
+            trace.append((int(stats.iters), fp.B.copy()))
+            if k > 100000:
+                break
+        eng.close()
+        return st, trace, fp
+    st1, tr1, fp1 = solve(1, [37])
+    st2, tr2, fp2 = solve(2, [37])
+    assert st1 == st2 == E.OPTIMAL
+    assert len(tr1) == len(tr2)
+    for (i1, B1), (i2, B2) in zip(tr1, tr2):
+        assert i1 == i2
+        np.testing.assert_array_equal(B1, B2)
+    np.testing.assert_allclose(fp1.x, fp2.x, rtol=0, atol=1e-9 * (1 + np.abs(fp1.x).max()))
+    # slices of 1, 2, 3, 5 iterations: open / close the pipeline all the time
+    st3, tr3, fp3 = solve(2, [1, 2, 3, 5])
+    assert st3 == E.OPTIMAL and tr3[-1][0] == tr1[-1][0]
+    np.testing.assert_array_equal(tr3[-1][1], tr1[-1][1])
+    assert abs(fp3.obj()) < 1e-9

@@ -128,7 +128,7 @@ def seam(view, which, max_iter=None):
     return ov, st_o, it_o, fp, st_g, stats, err_o, err_g
 
 
-@pytest.fixture(params=[0, 1], ids=["default-path", "explicit-inverse"])
+@pytest.fixture(params=[0, 1, 2], ids=["default-path", "explicit-inverse", "two-launch"])
 def pipeline(request):
     SEAM_PIPELINE[0] = request.param
     yield request.param
