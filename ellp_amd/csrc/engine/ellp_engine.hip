@@ -67,37 +67,43 @@ constexpr int ST_NEED_MAINT = 101;
 constexpr int WAVE = 64;
 
 struct DevState {
-    // ---- live words
-    int32_t status;      // ST_RUNNING or an ellp_status
+    // ---- head: six 16-byte groups that k_price2 fetches with one batch of vector loads (load_phead);
+    // keep the groups and their order in step with PHead
+    int32_t status;      // [0] ST_RUNNING or an ellp_status
     int32_t nan_flag;
     int32_t panic_code;  // which assert of the reference fired
-    int32_t cur;         // index of the current B^-1 buffer (written by k_update2 block 0 / refactor)
-    // ---- snapshot written by k_ftran2 block 0, read by k_update2 (which never writes it)
-    int32_t s_cur, s_at_lower, s_side, s_pad;
-    int64_t s_q, s_jq, s_r;
-    int64_t s_lv;  // dual: the leaving variable B_index[s_r] as k_ftran2 saw it
-    double s_rq, s_lambda0, s_delta, s_theta_d;
+    int32_t cur;         // index of the current B^-1 buffer (written by k_update2 block 0 / k_ftran_eta block 0 / refactor)
+    // snapshot written by k_ftran2 / k_ftran_eta block 0, read by k_update2 / k_price2 (which never write it)
+    int32_t s_cur, s_at_lower, s_side;  // [1]
+    int32_t tiny;        // maintenance request (tiny pivot, drift monitor, refused refresh), see ST_NEED_MAINT
+    int64_t s_q, s_jq;   // [2]
+    int64_t s_r;         // [3]
+    int64_t s_lv;        // dual: the leaving variable B_index[s_r] as k_ftran2 saw it
+    double s_rq, s_lambda0;  // [4]
+    int32_t fin;         // [5] k_ftran_eta: final status + 1 (0: none); the next kernel's leader makes it the status
+    int32_t usel;        // which of the two u buffers is current
+    int32_t s_nbq;       // Nb[s_q] as k_ftran_eta saw it
+    int32_t tiny_p;      // k_price2's bookkeeping: tiny pivot; k_ftran_eta relays it into `tiny`
+    double s_delta, s_theta_d;
     // ---- dual: leaving row for the coming iteration (written by k_dleave / k_update2<1> block 0)
     int64_t lr;
     double ldelta;
     int32_t lside, l_pad;
     // ---- refactorisation (single-block k_ref_pick -> k_ref_update)
     int32_t do_update;
-    int32_t tiny;  // k_update2's bookkeeping block: the pivot just taken was tiny (see ST_NEED_MAINT)
+    int32_t pad_du;
     int64_t r, refk;
     double d_r, alpha_r;
     // ---- results
     double lambda, obj;
     double drift;  // last k_drift_reduce: max|A_B (B^-1 a_q) - a_q| / max|a_q|
     // ---- two-launch pipeline (ellp_lagged.inc)
-    int32_t fin;        // k_ftran_eta: final status + 1 (0: none); the next kernel's leader makes it the status
-    int32_t tiny_p;     // k_price2's bookkeeping: tiny pivot; k_ftran_eta relays it into `tiny`
     int32_t pe_valid;   // k_price2 leader: k_ftran_eta has the eta update of the pivot just committed to apply
     int32_t f_src;      // k_price2 leader: the B^-1 buffer k_ftran_eta reads
     int64_t pe_r;
     double pe_d_r, pe_alpha_r;
-    int32_t usel, usel_next;  // which of the two u buffers is current / becomes current after k_ftran_eta
-    int32_t mv_pending, mv_pad;
+    int32_t usel_next;  // the u buffer that becomes current after k_ftran_eta
+    int32_t mv_pending;
     int64_t mv_r;       // deferred half of the column move: A_B[:, mv_r] <- aq_save, c_B[mv_r] <- cq_save
     double cq_save;
     double resid;  // last Newton-Schulz refresh: max|I - A_B W| before the step (k_resid_reduce)
