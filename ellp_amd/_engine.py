@@ -44,6 +44,10 @@ class Stats(C.Structure):
         return d
 
 
+# int fn(void *user, void *host_buffer, int64_t segment_bytes, int world)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+
 class EllpHipError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"{STATUS_NAME.get(status, status)}: {msg}")
@@ -118,6 +122,23 @@ def lib():
     L.ellp_engine_comm_init.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     L.ellp_engine_run_sharded.restype = C.c_int
     L.ellp_engine_run_sharded.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    L.ellp_engine_shard_columns.restype = C.c_int
+    L.ellp_engine_shard_columns.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.ellp_engine_set_exchange_callback.restype = C.c_int
+    L.ellp_engine_set_exchange_callback.argtypes = [C.c_void_p, EXCHANGE_FN, C.c_void_p]
+    L.ellp_engine_mailbox_export.restype = C.c_int
+    L.ellp_engine_mailbox_export.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_mailbox_connect.restype = C.c_int
+    L.ellp_engine_mailbox_connect.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_mailbox_selftest.restype = C.c_int
+    L.ellp_engine_mailbox_selftest.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.ellp_shard_select_compact.restype = C.c_int
+    L.ellp_shard_select_compact.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ellp_shard_pack_doubles.restype = C.c_int64
+    L.ellp_shard_pack_doubles.argtypes = [C.c_int64]
+    L.ellp_engine_shard_info.restype = C.c_int
+    L.ellp_engine_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -135,6 +156,19 @@ def qr_transposed(A, device=-1):
     if s != OPTIMAL:
         raise EllpHipError(s, err.value.decode())
     return piv, rd
+
+
+def shard_pack_doubles(ld):
+    return int(lib().ellp_shard_pack_doubles(int(ld)))
+
+
+def shard_select_compact(packs, world, ld, eps=1e-10):
+    """The ranks' selection on gathered packs (host build of the kernel's code).  Returns (verdict, q,
+    src_rank, src_slot): verdict 1 = the full exchange is needed."""
+    packs = np.ascontiguousarray(packs, dtype=np.float64)
+    q, sr, sc = C.c_int64(-1), C.c_int(-1), C.c_int(0)
+    v = lib().ellp_shard_select_compact(_p(packs), int(world), int(ld), float(eps), C.byref(q), C.byref(sr), C.byref(sc))
+    return int(v), int(q.value), int(sr.value), int(sc.value)
 
 
 def comm_unique_id(rccl_path=None):
@@ -341,6 +375,52 @@ class Engine:
         if s == ERR_DEVICE or s == ERR_ARG:
             raise EllpHipError(s, err.value.decode())
         return s, st, err.value.decode()
+
+    # ---- column-sharded storage (include/ellp_hip.h, ellp_engine_shard_columns)
+    def shard_columns(self, rank, world):
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_shard_columns(self._h, int(rank), int(world), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def set_exchange_callback(self, fn):
+        """fn(host_buffer_address, segment_bytes, world) -> 0 on success; all-gathers in place"""
+        def _cb(user, buf, seg, world):
+            try:
+                return int(fn(buf, seg, world))
+            except Exception:  # never unwind into C
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._xcb = EXCHANGE_FN(_cb)  # keep it alive as long as the engine
+        lib().ellp_engine_set_exchange_callback(self._h, self._xcb, None)
+
+    def mailbox_export(self):
+        buf = C.create_string_buffer(128)
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_mailbox_export(self._h, buf, err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+        return buf.raw
+
+    def mailbox_connect(self, all_handles):
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_mailbox_connect(self._h, bytes(all_handles), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def mailbox_selftest(self, rounds=8):
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_mailbox_selftest(self._h, int(rounds), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def shard_info(self):
+        out = (C.c_double * 6)()
+        lib().ellp_engine_shard_info(self._h, out)
+        return dict(full_exchanges=int(out[0]), column_requests=int(out[1]),
+                    transport={0: "none", 1: "rccl", 2: "mailbox", 3: "callback"}[int(out[2])],
+                    pack_doubles=int(out[3]), own=(int(out[4]), int(out[5])))
 
     def close(self):
         if self._h:

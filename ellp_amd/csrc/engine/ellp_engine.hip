@@ -106,6 +106,10 @@ struct DevState {
     int32_t mv_pending;
     int64_t mv_r;       // deferred half of the column move: A_B[:, mv_r] <- aq_save, c_B[mv_r] <- cq_save
     double cq_save;
+    // ---- column-sharded engines (ellp_shard.inc)
+    int64_t sh_q;        // k_sh_select: the entering position (-1: none)
+    int64_t sh_want_q;   // ST_NEED_COLUMN: the position whose column must be shipped
+    double sh_rq;        // reduced cost of sh_q (from the winner's pack)
     double resid;  // last Newton-Schulz refresh: max|I - A_B W| before the step (k_resid_reduce)
     int32_t need_rebuild;  // that residual was too large for a Newton-Schulz step: the host must rebuild
     int32_t pad_nr;
@@ -612,6 +616,7 @@ struct Ftran2Args {
     int64_t m, ld, nN;
     int nblocks, cpb;
     double eps;
+    const double *aq_cur;  // column-sharded engines: the entering position is st->sh_q (k_sh_select), its column is here
 };
 
 // NT = double2 per lane that hold one row (ceil(ld/128)); NT == 0: rows are streamed instead
@@ -642,7 +647,26 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     double xi0 = 0.0, lbi0 = 0.0, ubi0 = 0.0;
     int k0 = 0;
     double theta_d = 0.0;
-    if (MODE == 0) {
+    if (MODE == 0 && a.aq_cur) {
+        // column-sharded engine: the selection was made by k_sh_select from the gathered packs
+        const int64_t irow = wave_global < a.m ? wave_global : 0;
+        if (NT > 0) {
+            const double2 *row = reinterpret_cast<const double2 *>(W + irow * a.ld);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int64_t t = lane + u * WAVE;
+                const double2 wv = row[t < half ? t : 0];
+                wrow[u] = t < half ? wv : make_double2(0.0, 0.0);
+            }
+        }
+        bi0 = a.B_index[irow];
+        xi0 = a.x[bi0];
+        k0 = a.kind[bi0];
+        lbi0 = a.lb[bi0];
+        ubi0 = a.ub[bi0];
+        if (tid == 0) s_q = st->sh_q;
+        lds_barrier();
+    } else if (MODE == 0) {
         double *s_bk = reinterpret_cast<double *>(smem);
         double tmax = -INFINITY;
         double v0[4];  // first (normally only) batch of block maxima: issued before the row prefetch
@@ -846,7 +870,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     }
     const int at_lower = (MODE == 0) ? (a.Nb[q] == ELLP_NB_LOWER ? 1 : 0) : 0;
     const double sgn = at_lower ? -1.0 : 1.0;
-    const double2 *col = reinterpret_cast<const double2 *>(a.A_N + q * a.ld);
+    const double2 *col = reinterpret_cast<const double2 *>((MODE == 0 && a.aq_cur) ? a.aq_cur : a.A_N + q * a.ld);
     bool first = true;
     for (int64_t i = wave_global; i < a.m; i += nwaves, first = false) {
         const double2 *row = reinterpret_cast<const double2 *>(W + i * a.ld);
@@ -923,7 +947,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         if (MODE == 0) {
             const int64_t jq = a.N_index[q];
             st->s_jq = jq;
-            st->s_rq = a.xc.r(q);
+            st->s_rq = a.aq_cur ? st->sh_rq : a.xc.r(q);
             const int kk = a.kind[jq];  // primal…:305-311
             st->s_lambda0 = (kk == ELLP_BOUND_TWOSIDED) ? a.ub[jq] - a.lb[jq] : (kk == ELLP_BOUND_FIXED ? 0.0 : INFINITY);
         } else {
@@ -1140,6 +1164,8 @@ struct Update2Args {
     int stage_lds;
     double ill_tol;   // > 0: after a pivot with |alpha_r| < ill_tol * max|alpha| stop for maintenance
     double eps;
+    const double *aq_cur;   // column-sharded engines: the entering column (A_N holds only positions [own0, own1))
+    int64_t own0, own1;
 };
 
 // NR = double2 per thread per row (ceil(ld/512)); NR == 0: rows are streamed after the fold
@@ -1389,7 +1415,21 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                     u2[t] = w;
                 }
             }
-            swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
+            if (a.aq_cur) {
+                // column-sharded: the owner of position q takes the leaving column (A_B is replicated), every
+                // rank puts the entering column into A_B[:, r]
+                const bool mine = q >= a.own0 && q < a.own1;
+                double2 *cn = reinterpret_cast<double2 *>(a.A_N + (mine ? q : a.own0) * a.ld);
+                double2 *cb = reinterpret_cast<double2 *>(a.A_B + r * a.ld);
+                const double2 *aq = reinterpret_cast<const double2 *>(a.aq_cur);
+                for (int64_t t = tid; t < (a.ld >> 1); t += 256) {
+                    const double2 lv = cb[t];
+                    if (mine) cn[t] = lv;
+                    cb[t] = aq[t];
+                }
+            } else {
+                swap_columns(a.A_N, a.A_B, q, r, a.ld, tid);
+            }
             if (tid == 0) {
                 const double tc = a.c_N[q];
                 a.c_N[q] = a.c_B[r];
@@ -1583,6 +1623,7 @@ __global__ __launch_bounds__(256) void k_btran_reduce(BtranArgs a) {
 // a tiny pivot — when max|t| exceeds drift_tol * max|a_q|.
 struct DriftArgs {
     const double *A_B, *A_N, *d;
+    const double *aq_cur;  // column-sharded engines: the entering column
     double *upart;
     DevState *st;
     int64_t m, ld;
@@ -1612,7 +1653,7 @@ __global__ __launch_bounds__(1024) void k_drift_reduce(DriftArgs a) {
     if (st->status != ST_RUNNING) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double sgn = st->s_at_lower ? -1.0 : 1.0;  // alpha = sgn * d (k_ftran2 stores d = +-alpha)
-    const double *aq = a.A_N + st->s_q * a.ld;
+    const double *aq = a.aq_cur ? a.aq_cur : a.A_N + st->s_q * a.ld;
     double res = 0.0, scale = 0.0;
     for (int64_t i = tid; i < a.m; i += 1024) {
         double t = 0.0;
@@ -2129,6 +2170,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
 }
 
 #include "ellp_lagged.inc"
+#include "ellp_shard.inc"
 #include "ellp_small.inc"
 
 }  // namespace
@@ -2178,6 +2220,24 @@ struct ellp_engine {
     int64_t seg = 0;
     hipStream_t own_stream = nullptr;
     bool need_dleave = true;
+    // column-sharded storage of A_N (ellp_shard.inc)
+    bool colshard = false;
+    int64_t own0 = 0, own1 = 0;          // nonbasic positions stored and priced here
+    double *A_N_store = nullptr;          // the allocation behind the virtual base e->A_N
+    double *packs = nullptr, *aq_cur = nullptr;  // gathered packs (world * pack_doubles), entering column
+    int64_t slot_doubles = 0;             // doubles per exchange slot = max(pack, full pricing segment)
+    int transport = 0;                    // 0 none, 1 RCCL, 2 peer-to-peer mailbox, 3 host callback (tests, gloo)
+    ellp_exchange_fn xfn = nullptr;
+    void *xuser = nullptr;
+    std::vector<char> xhost;              // staging for the callback transport
+    // mailbox
+    double *mbox = nullptr;               // own mailbox (uncached): [parity][sender] slots
+    unsigned long long *mflags = nullptr; // own flags: [parity][sender]
+    double **d_peer_slots = nullptr;      // device arrays of the peers' mapped bases
+    unsigned long long **d_peer_flags = nullptr;
+    std::vector<void *> ipc_opened;
+    unsigned long long mgen = 0;
+    uint64_t full_exchanges = 0, column_requests = 0;
     // small LPs (m <= 128): the reference's LU-per-iteration loop in one persistent workgroup (ellp_small.inc)
     bool small = false;      // run() uses k_small
     bool w_valid = true;     // the explicit inverse W (not kept by k_small) matches A_B
@@ -2369,6 +2429,7 @@ void launch_ftran2(ellp_engine *e) {
     a.x = e->x; a.lb = e->lb; a.ub = e->ub;
     a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.cpb = e->cpb; a.eps = e->eps;
+    a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr;
     const dim3 g(e->ftran_blocks), b(256);
     const int64_t nt = ((e->ld >> 1) + 63) / 64;  // double2 per lane for one row
     if (nt <= 4) hipLaunchKernelGGL((k_ftran2<MODE, 4>), g, b, e->ftran_lds, e->stream, a);
@@ -2386,6 +2447,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd2_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
+    a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
@@ -2468,6 +2530,7 @@ void launch_dleave(ellp_engine *e);
 // x_B from the freshly maintained B^-1 (see k_resync_part)
 void launch_resync(ellp_engine *e) {
     if (e->nN <= 0) return;
+    if (e->colshard) return;  // b - A_N x_N would need every rank's columns (a reduction over the ranks): not done
     ResyncArgs a{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
                  e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles};
     (void)hipMemsetAsync(e->maxbits, 0, 2 * sizeof(unsigned long long), e->stream);
@@ -2555,7 +2618,7 @@ void launch_drift_check(ellp_engine *e) {
     if (++e->since_drift < (uint64_t)e->drift_every) return;
     e->since_drift = 0;
     e->drift_checks += 1;
-    DriftArgs a{e->A_B, e->A_N, e->d, e->upart, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles, e->drift_tol};
+    DriftArgs a{e->A_B, e->A_N, e->d, e->colshard ? e->aq_cur : nullptr, e->upart, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles, e->drift_tol};
     const int64_t half = e->ld >> 1;
     hipLaunchKernelGGL(k_drift_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0,
                        e->stream, a);
@@ -2809,6 +2872,9 @@ void ellp_engine_destroy(ellp_engine *e) {
 #endif
     e->stream = e->own_stream;
     if (e->comm && e->rccl) (void)e->rccl->CommDestroy(e->comm);
+    for (void *p : e->ipc_opened) (void)hipIpcCloseMemHandle(p);
+    if (e->mbox) (void)hipFree(e->mbox);
+    if (e->mflags) (void)hipFree(e->mflags);
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->h_st) (void)hipHostFree(e->h_st);
     if (e->h_look) (void)hipHostFree(e->h_look);
@@ -3229,6 +3295,8 @@ ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
     return ELLP_OPTIMAL;
 }
 
+static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen);
+
 ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
     if (errbuf && errlen) errbuf[0] = 0;
@@ -3244,6 +3312,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         result = run_small(e, max_iters, errbuf, errlen);
     } else {
         uint64_t remaining = max_iters;
+        if (e->colshard) return run_colsharded(e, max_iters, stats, errbuf, errlen);
         if (e->world != 1) {
             set_err(errbuf, errlen, "a sharded engine is driven with ellp_engine_step + an all-gather (ellp_amd/dist.py)");
             return ELLP_ERR_ARG;
@@ -3711,8 +3780,13 @@ ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const v
     const RcclApi *api = load_rccl(rccl_path, errbuf, errlen);
     if (!api) return ELLP_ERR_DEVICE;
     HIPCHK(hipSetDevice(e->device));
-    const ellp_status s = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // engine-owned buffer
-    if (s != ELLP_OPTIMAL) return s;
+    if (!e->colshard) {
+        const ellp_status s = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // engine-owned buffer
+        if (s != ELLP_OPTIMAL) return s;
+    } else if (rank != e->rank || world != e->world) {
+        set_err(errbuf, errlen, "rank/world differ from ellp_engine_shard_columns");
+        return ELLP_ERR_ARG;
+    }
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     if (e->comm) {
@@ -3726,12 +3800,341 @@ ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const v
         return ELLP_ERR_DEVICE;
     }
     e->rccl = api;
+    if (e->colshard && e->transport == 0) e->transport = 1;
     return ELLP_OPTIMAL;
+}
+
+// ---- column-sharded storage: setup, transports, loop (kernels: ellp_shard.inc) ---------------------
+ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char *errbuf, size_t errlen) {
+    if (!e || world < 1 || rank < 0 || rank >= world) return ELLP_ERR_ARG;
+    if (errbuf && errlen) errbuf[0] = 0;
+    if (e->kind != ELLP_ENGINE_PRIMAL) {
+        set_err(errbuf, errlen, "column-sharded storage is implemented for the primal loop");
+        return ELLP_ERR_ARG;
+    }
+    if (world * SH_KC > WAVE) {
+        set_err(errbuf, errlen, "at most %d ranks", WAVE / SH_KC);
+        return ELLP_ERR_ARG;
+    }
+    if (e->colshard) {
+        set_err(errbuf, errlen, "the columns are already sharded");
+        return ELLP_ERR_ARG;
+    }
+    const ellp_status s0 = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // rank, world, nbs, seg, X
+    if (s0 != ELLP_OPTIMAL) return s0;
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t ld = e->ld;
+    int64_t a0 = (int64_t)rank * e->nbs * e->cpb, a1 = (int64_t)(rank + 1) * e->nbs * e->cpb;
+    if (a0 > e->nN) a0 = e->nN;
+    if (a1 > e->nN) a1 = e->nN;
+    const int64_t nloc = a1 - a0;
+    double *loc = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&loc), sizeof(double) * (size_t)(ld * (nloc > 0 ? nloc : 1))));
+    if (nloc > 0)
+        HIPCHK(hipMemcpy(loc, e->A_N + a0 * ld, sizeof(double) * (size_t)(ld * nloc), hipMemcpyDeviceToDevice));
+    // release the full A_N: it is one of e->allocs
+    for (auto &p : e->allocs)
+        if (p == e->A_N) {
+            (void)hipFree(p);
+            p = loc;
+        }
+    e->A_N_store = loc;
+    e->A_N = loc - a0 * ld;  // virtual base: only [own0, own1) may be dereferenced
+    e->own0 = a0;
+    e->own1 = a1;
+    const int64_t pd = pack_doubles(ld);
+    e->slot_doubles = pd > e->seg ? pd : e->seg;
+    HIPCHK(dmalloc(e, &e->packs, (size_t)(pd * world)));
+    HIPCHK(dmalloc(e, &e->aq_cur, (size_t)ld));
+    HIPCHK(hipMemset(e->packs, 0, sizeof(double) * (size_t)(pd * world)));
+    HIPCHK(hipMemset(e->aq_cur, 0, sizeof(double) * (size_t)ld));
+    e->colshard = true;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_set_exchange_callback(ellp_engine *e, ellp_exchange_fn fn, void *user) {
+    if (!e) return ELLP_ERR_ARG;
+    e->xfn = fn;
+    e->xuser = user;
+    if (fn) e->transport = 3;
+    return ELLP_OPTIMAL;
+}
+
+int ellp_shard_select_compact(const double *packs, int world, int64_t ld, double eps, int64_t *q, int *src_rank, int *src_slot) {
+    if (!packs || !q || !src_rank || !src_slot || world < 1 || world * SH_KC > WAVE) return -1;
+    long long qq = -1;
+    const int v = shard_select_compact(packs, world, ld, eps, &qq, src_rank, src_slot);
+    *q = qq;
+    return v;
+}
+int64_t ellp_shard_pack_doubles(int64_t ld) { return pack_doubles(ld); }
+
+ellp_status ellp_engine_shard_info(ellp_engine *e, double *out6) {
+    if (!e || !out6) return ELLP_ERR_ARG;
+    out6[0] = (double)e->full_exchanges;
+    out6[1] = (double)e->column_requests;
+    out6[2] = (double)e->transport;
+    out6[3] = (double)pack_doubles(e->ld);
+    out6[4] = (double)e->own0;
+    out6[5] = (double)e->own1;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_mailbox_export(ellp_engine *e, void *handles_out, char *errbuf, size_t errlen) {
+    if (!e || !handles_out || !e->colshard) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    static_assert(sizeof(hipIpcMemHandle_t) == ELLP_IPC_HANDLE_BYTES, "IPC handle size");
+    if (!e->mbox) {
+        const size_t slots = sizeof(double) * (size_t)(2 * e->world * e->slot_doubles);
+        void *p = nullptr, *f = nullptr;
+        // uncached: stores of a peer must not be hidden by this GPU's L2, polls must not hit stale lines
+        HIPCHK(hipExtMallocWithFlags(&p, slots, hipDeviceMallocUncached));
+        HIPCHK(hipExtMallocWithFlags(&f, sizeof(unsigned long long) * 2 * 64, hipDeviceMallocUncached));
+        HIPCHK(hipMemset(p, 0, slots));
+        HIPCHK(hipMemset(f, 0, sizeof(unsigned long long) * 2 * 64));
+        e->mbox = static_cast<double *>(p);
+        e->mflags = static_cast<unsigned long long *>(f);
+    }
+    hipIpcMemHandle_t h[2];
+    HIPCHK(hipIpcGetMemHandle(&h[0], e->mbox));
+    HIPCHK(hipIpcGetMemHandle(&h[1], e->mflags));
+    memcpy(handles_out, h, sizeof(h));
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_mailbox_connect(ellp_engine *e, const void *all_handles, char *errbuf, size_t errlen) {
+    if (!e || !all_handles || !e->mbox) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<double *> slots((size_t)e->world);
+    std::vector<unsigned long long *> flags((size_t)e->world);
+    const hipIpcMemHandle_t *h = static_cast<const hipIpcMemHandle_t *>(all_handles);
+    for (int r = 0; r < e->world; ++r) {
+        if (r == e->rank) {
+            slots[r] = e->mbox;
+            flags[r] = e->mflags;
+            continue;
+        }
+        void *p = nullptr, *f = nullptr;
+        HIPCHK(hipIpcOpenMemHandle(&p, h[2 * r], hipIpcMemLazyEnablePeerAccess));
+        e->ipc_opened.push_back(p);
+        HIPCHK(hipIpcOpenMemHandle(&f, h[2 * r + 1], hipIpcMemLazyEnablePeerAccess));
+        e->ipc_opened.push_back(f);
+        slots[r] = static_cast<double *>(p);
+        flags[r] = static_cast<unsigned long long *>(f);
+    }
+    HIPCHK(dmalloc(e, &e->d_peer_slots, (size_t)e->world));
+    HIPCHK(dmalloc(e, &e->d_peer_flags, (size_t)e->world));
+    HIPCHK(hipMemcpy(e->d_peer_slots, slots.data(), sizeof(double *) * (size_t)e->world, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_peer_flags, flags.data(), sizeof(unsigned long long *) * (size_t)e->world, hipMemcpyHostToDevice));
+    e->transport = 2;
+    return ELLP_OPTIMAL;
+}
+
+namespace {
+// all-gather `n` doubles per rank: src = this rank's segment, dst = world * n doubles (dst + rank * n may be src)
+ellp_status shard_exchange(ellp_engine *e, const double *src, double *dst, int64_t n, char *errbuf, size_t errlen) {
+    if (e->world == 1) {
+        if (dst + (int64_t)e->rank * n != src)
+            HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, e->stream));
+        return ELLP_OPTIMAL;
+    }
+    if (e->transport == 2) {
+        e->mgen += 1;
+        MboxArgs a{e->d_peer_slots, e->d_peer_flags, src, dst, e->st, n, e->rank, e->world, e->mgen, 300000000LL /* 3 s */};
+        // the slot stride is slot_doubles, not n: both sides use slot_doubles
+        a.n = n;
+        hipLaunchKernelGGL(k_mbox_push, dim3((unsigned)e->world), dim3(256), 0, e->stream, a, e->slot_doubles);
+        hipLaunchKernelGGL(k_mbox_wait, dim3((unsigned)e->world), dim3(256), 0, e->stream, a, e->slot_doubles);
+        return ELLP_OPTIMAL;
+    }
+    if (e->transport == 1 && e->comm && e->rccl) {
+        if (dst + (int64_t)e->rank * n != src)
+            HIPCHK(hipMemcpyAsync(dst + (int64_t)e->rank * n, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, e->stream));
+        const ncclResult_t rc = e->rccl->AllGather(dst + (int64_t)e->rank * n, dst, (size_t)n, ncclDouble, e->comm, e->stream);
+        if (rc != ncclSuccess) {
+            set_err(errbuf, errlen, "ncclAllGather: %s", e->rccl->GetErrorString(rc));
+            return ELLP_ERR_DEVICE;
+        }
+        return ELLP_OPTIMAL;
+    }
+    if (e->transport == 3 && e->xfn) {
+        const size_t segb = sizeof(double) * (size_t)n;
+        e->xhost.resize(segb * (size_t)e->world);
+        HIPCHK(hipMemcpyAsync(e->xhost.data() + segb * (size_t)e->rank, src, segb, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->xfn(e->xuser, e->xhost.data(), (int64_t)segb, e->world) != 0) {
+            set_err(errbuf, errlen, "the exchange callback failed");
+            return ELLP_ERR_DEVICE;
+        }
+        HIPCHK(hipMemcpyAsync(dst, e->xhost.data(), segb * (size_t)e->world, hipMemcpyHostToDevice, e->stream));
+        return ELLP_OPTIMAL;
+    }
+    set_err(errbuf, errlen, "no exchange transport has been set up (RCCL communicator, mailbox or callback)");
+    return ELLP_ERR_ARG;
+}
+
+void launch_pack(ellp_engine *e, int forced) {
+    PackArgs a{};
+    a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.N_index = e->N_index;
+    a.pack = e->packs + (int64_t)e->rank * pack_doubles(e->ld);
+    a.st = e->st; a.ld = e->ld; a.nN = e->nN; a.own0 = e->own0; a.own1 = e->own1;
+    a.block0 = e->rank * e->nbs;
+    int mine = e->nblocks - a.block0;
+    if (mine > e->nbs) mine = e->nbs;
+    if (mine < 0) mine = 0;
+    a.nblk = mine; a.cpb = e->cpb; a.forced = forced; a.eps = e->eps;
+    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, e->stream, a);
+}
+void launch_select(ellp_engine *e, int mode) {
+    SelectArgs a{};
+    a.packs = e->packs; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.N_index = e->N_index; a.A_N = e->A_N;
+    a.aq_cur = e->aq_cur; a.st = e->st; a.ld = e->ld; a.nN = e->nN; a.own0 = e->own0; a.own1 = e->own1;
+    a.world = e->world; a.nblocks = e->nblocks; a.cpb = e->cpb; a.mode = mode; a.eps = e->eps;
+    hipLaunchKernelGGL(k_sh_select, dim3(1), dim3(256), sizeof(double) * (size_t)e->nblocks + 16, e->stream, a);
+}
+// the part of an iteration behind the selection: FTRAN with the given column, drift monitor, eta update
+void launch_sharded_tail(ellp_engine *e) {
+    {
+        Prof p(e, ELLP_K_FTRAN);
+        launch_ftran2<0>(e);
+    }
+    launch_drift_check(e);
+    {
+        Prof p(e, ELLP_K_UPDATE);
+        launch_update2<0>(e, 1);
+    }
+    e->since_btran += 1;
+    e->since_refactor += 1;
+    e->enqueued += 1;
+}
+ellp_status launch_sharded_iteration(ellp_engine *e, char *errbuf, size_t errlen) {
+    const bool full_btran = !e->u_valid || e->since_btran >= (uint64_t)e->btran_refresh;
+    if (full_btran) {
+        Prof p(e, ELLP_K_BTRAN);
+        launch_btran(e);
+        e->since_btran = 0;
+        e->u_valid = true;
+    }
+    {
+        Prof p(e, ELLP_K_PRICE);
+        launch_price<0>(e);
+    }
+    {
+        Prof p(e, ELLP_K_SELECT);
+        launch_pack(e, 0);
+        const int64_t pd = pack_doubles(e->ld);
+        const ellp_status s = shard_exchange(e, e->packs + (int64_t)e->rank * pd, e->packs, pd, errbuf, errlen);
+        if (s != ELLP_OPTIMAL) return s;
+        launch_select(e, 1);
+    }
+    launch_sharded_tail(e);
+    return ELLP_OPTIMAL;
+}
+}  // namespace
+
+ellp_status ellp_engine_mailbox_selftest(ellp_engine *e, int rounds, char *errbuf, size_t errlen) {
+    if (!e || e->transport != 2) return ELLP_ERR_ARG;
+    HIPCHK(hipSetDevice(e->device));
+    const int64_t n = pack_doubles(e->ld);
+    std::vector<double> mine((size_t)n), all((size_t)(n * e->world));
+    double *d_src = e->packs + (int64_t)e->rank * n;
+    for (int round = 0; round < rounds; ++round) {
+        for (int64_t i = 0; i < n; ++i) mine[(size_t)i] = (double)(e->rank * 1000003 + round * 7919) + (double)i * 0.5;
+        HIPCHK(hipMemcpyAsync(d_src, mine.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+        const ellp_status s = shard_exchange(e, d_src, e->packs, n, errbuf, errlen);
+        if (s != ELLP_OPTIMAL) return s;
+        HIPCHK(hipMemcpyAsync(all.data(), e->packs, sizeof(double) * (size_t)(n * e->world), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (e->h_st->status != ST_RUNNING) {
+            set_err(errbuf, errlen, "mailbox self-test: a wait timed out (round %d)", round);
+            return ELLP_ERR_DEVICE;
+        }
+        for (int r = 0; r < e->world; ++r)
+            for (int64_t i = 0; i < n; ++i) {
+                const double want = (double)(r * 1000003 + round * 7919) + (double)i * 0.5;
+                if (all[(size_t)(r * n + i)] != want) {
+                    set_err(errbuf, errlen, "mailbox self-test: word %lld of rank %d's segment is wrong in round %d", (long long)i, r, round);
+                    return ELLP_ERR_DEVICE;
+                }
+            }
+    }
+    HIPCHK(hipMemset(e->packs, 0, sizeof(double) * (size_t)(n * e->world)));
+    return ELLP_OPTIMAL;
+}
+
+// the loop of a column-sharded engine (collective: every rank passes the same max_iters)
+static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen) {
+    auto t0 = std::chrono::steady_clock::now();
+    ellp_stats local;
+    ellp_stats *sp = stats ? stats : &local;
+    ellp_status result = ellp_engine_poll(e, sp, errbuf, errlen);
+    const uint64_t iters0 = sp->iters;
+    uint64_t remaining = max_iters;
+    const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 32;
+    int64_t period = e->refactor_period > 0 ? e->refactor_period : default_period(e);
+    auto rearm = [&]() {
+        const int32_t running = ST_RUNNING;
+        (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        e->h_st->status = ST_RUNNING;
+    };
+    while (result == ELLP_MAXITER && remaining > 0 && e->nN > 0) {
+        const uint64_t batch = remaining < poll ? remaining : poll;
+        for (uint64_t k = 0; k < batch; ++k) {
+            if (e->since_refactor >= (uint64_t)period) maintain_inverse(e);
+            const ellp_status s = launch_sharded_iteration(e, errbuf, errlen);
+            if (s != ELLP_OPTIMAL) return s;
+        }
+        // read back; the two internal requests of the selection are serviced here, one iteration at a time
+        for (;;) {
+            HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipGetLastError());
+            prof_collect(e);
+            reconcile_counters(e);
+            const int stt = e->h_st->status;
+            if (stt == ST_NEED_FULL) {
+                // ties reach below the gap: gather the complete pricing output and fold it in full
+                rearm();
+                e->full_exchanges += 1;
+                const ellp_status s = shard_exchange(e, e->X + (int64_t)e->rank * e->seg, e->X, e->seg, errbuf, errlen);
+                if (s != ELLP_OPTIMAL) return s;
+                launch_select(e, 2);
+                launch_sharded_tail(e);
+                continue;
+            }
+            if (stt == ST_NEED_COLUMN) {
+                rearm();
+                e->column_requests += 1;
+                launch_pack(e, 1);
+                const int64_t pd = pack_doubles(e->ld);
+                const ellp_status s = shard_exchange(e, e->packs + (int64_t)e->rank * pd, e->packs, pd, errbuf, errlen);
+                if (s != ELLP_OPTIMAL) return s;
+                launch_select(e, 3);
+                launch_sharded_tail(e);
+                continue;
+            }
+            break;
+        }
+        (void)service_maintenance_request(e);
+        result = e->h_st->status == ST_RUNNING ? ELLP_MAXITER : status_message(*e->h_st, errbuf, errlen);
+        fill_stats(e, sp);
+        const uint64_t done = sp->iters - iters0;
+        remaining = done < max_iters ? max_iters - done : 0;
+    }
+    if (e->nN == 0) result = ELLP_OPTIMAL;
+    if (stats) stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return result;
 }
 
 ellp_status ellp_engine_run_sharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf,
                                     size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
+    if (e->colshard) {
+        if (errbuf && errlen) errbuf[0] = 0;
+        HIPCHK(hipSetDevice(e->device));
+        return run_colsharded(e, max_iters, stats, errbuf, errlen);
+    }
     if (!e->comm || !e->rccl) {
         set_err(errbuf, errlen, "ellp_engine_comm_init has not been called");
         return ELLP_ERR_ARG;

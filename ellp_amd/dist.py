@@ -1,4 +1,12 @@
-"""Column-block pricing sharded over several GPUs, one process per GPU.
+"""Column-block sharding over several GPUs, one process per GPU.
+
+Primal engines (the default with more than one rank): the nonbasic columns are sharded in STORAGE as
+well as in pricing — each rank keeps only its block of A_N — and the per-iteration exchange is one
+small "pack" per rank (its best candidates with their columns), carried by a peer-to-peer mailbox
+(hipIpc-mapped memory, direct stores over xGMI), by RCCL, or — for gloo tests — by a host callback; the
+loop runs inside the library (`ellp_engine_run_sharded`, ellp_amd/csrc/engine/ellp_shard.inc).
+
+Dual engines and `colshard=False` (the round-1 scheme, kept as a cross-check):
 
 The nonbasic positions are cut into `world` contiguous blocks.  Per simplex iteration every
 rank prices its own block (k_price), then ONE all-gather of the engine's exchange buffer
@@ -65,7 +73,7 @@ class ShardedEngine:
     runs here, one `all_gather_into_tensor` per iteration (the only choice with backend gloo; also
     the fallback if RCCL cannot be bound).  ELLP_DIST_EXCHANGE overrides."""
 
-    def __init__(self, kind, fp, opts=None, group=None, exchange=None):
+    def __init__(self, kind, fp, opts=None, group=None, exchange=None, colshard=None):
         import os
         import torch
         import torch.distributed as dist
@@ -76,7 +84,21 @@ class ShardedEngine:
             self.rank, self.world = 0, 1
         self.eng = E.Engine(kind, fp, opts)
         backend = dist.get_backend(group) if self.world > 1 else None
-        exchange = exchange or os.environ.get("ELLP_DIST_EXCHANGE") or ("rccl" if backend == "nccl" else "torch")
+        exchange = exchange or os.environ.get("ELLP_DIST_EXCHANGE")
+        if colshard is None:
+            env = os.environ.get("ELLP_DIST_COLSHARD")
+            colshard = (kind == E.ENGINE_PRIMAL and self.world > 1) if env is None else env == "1"
+        self.colshard = bool(colshard) and kind == E.ENGINE_PRIMAL
+        self.exchange_name = None
+        self.stream = None
+        if self.colshard:
+            self.direct = True
+            self._init_colshard(backend, exchange)
+            return
+        exchange = exchange or ("rccl" if backend == "nccl" else "torch")
+        if exchange in ("mailbox", "callback"):
+            exchange = "rccl" if backend == "nccl" else "torch"
+        self.exchange_name = "all-gather of the whole pricing output (" + exchange + ")"
         self.direct = False
         if exchange == "rccl":
             self.direct = self._init_direct(backend)
@@ -99,6 +121,78 @@ class ShardedEngine:
         self.eng.set_stream(self.stream.cuda_stream)
         self.mine = self.full[self.rank * seg:(self.rank + 1) * seg]  # this rank's slice (a view)
         self.nccl = self.world > 1 and backend == "nccl"
+
+    def _vote(self, ok, dev):
+        """True iff every rank succeeded: the ranks must agree on the transport they use"""
+        if self.world == 1:
+            return bool(ok)
+        flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
+    def _init_colshard(self, backend, exchange):
+        """Sharded storage of A_N + the pack exchange.  Transport: the peer-to-peer mailbox if every rank
+        can map every peer's memory and a self-test of the hand-off passes (every word of 8 exchanges
+        checked), else RCCL (backend nccl), else a host callback over the process group (gloo)."""
+        torch, dist = self.torch, self.dist
+        dev = "cuda" if backend == "nccl" else "cpu"
+        self.eng.shard_columns(self.rank, self.world)
+        want = exchange or ("auto" if backend == "nccl" else "callback")
+        if self.world == 1:
+            self.eng.set_exchange_callback(lambda buf, seg, world: 0)
+            self.exchange_name = "none (one rank)"
+            return
+        if want in ("auto", "mailbox"):
+            ok = True
+            handles = None
+            try:
+                handles = self.eng.mailbox_export()
+            except Exception:
+                ok = False
+            if self._vote(ok, dev):
+                mine = torch.frombuffer(bytearray(handles), dtype=torch.uint8).to(dev)
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine, group=self.group)
+                blob = b"".join(bytes(p.cpu().numpy().tobytes()) for p in parts)
+                try:
+                    self.eng.mailbox_connect(blob)
+                except Exception:
+                    ok = False
+                if self._vote(ok, dev):
+                    if self.world > 1:
+                        dist.barrier(group=self.group)
+                    try:
+                        self.eng.mailbox_selftest(8)
+                    except Exception:
+                        ok = False
+                    if self._vote(ok, dev):
+                        self.exchange_name = "pack exchange over the peer-to-peer mailbox"
+                        return
+            if want == "mailbox":
+                raise RuntimeError("the peer-to-peer mailbox could not be set up on every rank")
+        if backend == "nccl" and want in ("auto", "rccl", "mailbox"):
+            if self._init_direct(backend):
+                self.exchange_name = "pack exchange by ncclAllGather"
+                return
+        # host callback over the process group (gloo; also the last resort with nccl)
+        def gather(buf, seg, world):
+            import ctypes
+            import numpy as np
+            arr = np.ctypeslib.as_array((ctypes.c_uint8 * (seg * world)).from_address(buf))
+            t = torch.from_numpy(arr)
+            mine_ = t[self.rank * seg:(self.rank + 1) * seg].clone()
+            if backend == "nccl":
+                g = mine_.cuda()
+                parts_ = [torch.empty_like(g) for _ in range(world)]
+                dist.all_gather(parts_, g, group=self.group)
+                t.copy_(torch.cat(parts_).cpu())
+            else:
+                parts_ = [torch.empty_like(mine_) for _ in range(world)]
+                dist.all_gather(parts_, mine_, group=self.group)
+                t.copy_(torch.cat(parts_))
+            return 0
+        self.eng.set_exchange_callback(gather)
+        self.exchange_name = "pack exchange staged through the host (process group " + str(backend) + ")"
 
     def _init_direct(self, backend):
         """Unique id from rank 0 to everyone over the process group, then ncclCommInitRank in the

@@ -221,6 +221,45 @@ ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const v
 ellp_status ellp_engine_run_sharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf,
                                     size_t errbuf_len);
 
+/*
+ * Column-block sharding with SHARDED STORAGE (primal engines): after
+ * ellp_engine_shard_columns(e, rank, world) the engine keeps only the nonbasic columns of its own block
+ * (the rest of A_N is released) and ellp_engine_run_sharded() exchanges, once per iteration, one small
+ * "pack" per rank — its maximal Dantzig key and the at most two candidates within 6 EPS of it, each with
+ * its column (64 KB at m = 4000) — instead of the whole pricing output; when ties reach further the loop
+ * falls back, for that iteration, to gathering the complete pricing output (exact in every case, see
+ * ellp_amd/csrc/engine/ellp_shard.inc).  Transports for the exchange, chosen by what has been set up:
+ *   ellp_engine_comm_init          RCCL all-gather on the engine's stream
+ *   ellp_engine_mailbox_*          peer-to-peer mailbox: every rank stores its pack directly into every
+ *                                  peer's memory (hipIpc-mapped, over xGMI) and raises a flag there; export
+ *                                  gives this rank's two IPC handles (2 x 64 bytes: slots, flags), connect
+ *                                  takes those of all ranks in rank order (world x 128 bytes)
+ *   ellp_engine_set_exchange_callback   the library stages the segments through host memory and calls
+ *                                  fn(user, host_buffer, segment_bytes, world) to all-gather them in place
+ *                                  (own segment at rank * segment_bytes); for tests and gloo
+ * All of them are collective in the usual sense: every rank makes the same calls in the same order.
+ */
+typedef int (*ellp_exchange_fn)(void *user, void *host_buffer, int64_t segment_bytes, int world);
+ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char *errbuf, size_t errbuf_len);
+ellp_status ellp_engine_set_exchange_callback(ellp_engine *e, ellp_exchange_fn fn, void *user);
+#define ELLP_IPC_HANDLE_BYTES 64
+ellp_status ellp_engine_mailbox_export(ellp_engine *e, void *handles_out /* 2 x 64 bytes */, char *errbuf, size_t errbuf_len);
+ellp_status ellp_engine_mailbox_connect(ellp_engine *e, const void *all_handles /* world x 128 bytes */, char *errbuf,
+                                        size_t errbuf_len);
+/* one exchange of a test pattern through the mailbox, every word checked; ELLP_OPTIMAL if it arrived intact */
+ellp_status ellp_engine_mailbox_selftest(ellp_engine *e, int rounds, char *errbuf, size_t errbuf_len);
+/* counters of the sharded loop: [0] iterations that needed the full exchange, [1] column requests,
+ * [2] transport (1 RCCL, 2 mailbox, 3 callback), [3] doubles per pack, [4] first own position, [5] one past the last */
+ellp_status ellp_engine_shard_info(ellp_engine *e, double *out6);
+/* The selection the ranks run on the gathered packs, as a host function (the same source the kernel
+ * k_sh_select compiles; no device needed): packs = world * ellp_shard_pack_doubles(ld) doubles, each pack
+ * [M_s, count, overflow, 0, then `count` records of (key, N.index, position, r_j, column[ld])].
+ * Returns 1 if the packs are not conclusive (the full exchange is needed), 0 with *q = entering position
+ * (-1: none) and the (rank, slot) of the pack that holds its column, -1 on bad arguments. */
+int ellp_shard_select_compact(const double *packs, int world, int64_t ld, double eps, int64_t *q, int *src_rank,
+                              int *src_slot);
+int64_t ellp_shard_pack_doubles(int64_t ld);
+
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
 enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_TAP_KEY = 4,

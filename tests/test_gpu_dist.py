@@ -78,18 +78,29 @@ def _worker(rank, world, port, q):
             st_ref, stats_ref, _ = ref.run(cap)
             ref.read_point()
             ref.close()
-            fp = make()
-            sh = ShardedEngine(kind, fp, opts)
-            st, stats, msg = sh.run(cap, poll_interval=8)
-            sh.read_point()
-            sh.close()
-            out[name] = dict(
-                same_status=(st == st_ref), status=int(st), iters=int(stats.iters), iters_ref=int(stats_ref.iters),
-                expect=(int(st_ref) if cap < 100000 else E.OPTIMAL),
-                same_B=bool(np.array_equal(fp.B, ref_fp.B)), same_N=bool(np.array_equal(fp.N, ref_fp.N)),
-                # same pivots; x to rounding: the two drivers may refresh B^-1 (and with it x_B) at different
-                # moments, e.g. inside a batch that a maintenance request has voided
-                same_x=bool(np.allclose(fp.x, ref_fp.x, rtol=0, atol=1e-10 * (1 + np.abs(ref_fp.x).max()))), msg=msg)
+            variants = [("replicated", dict(colshard=False))]
+            if kind == E.ENGINE_PRIMAL:
+                # sharded STORAGE of A_N + the pack exchange (ellp_shard.inc), over both transports a
+                # one-GPU box can run: the host callback (gloo) and the peer-to-peer mailbox (hipIpc
+                # mapping of the other process's memory; here both processes sit on GPU 0)
+                variants += [("colshard-callback", dict(colshard=True, exchange="callback")),
+                             ("colshard-mailbox", dict(colshard=True, exchange="mailbox"))]
+            for vname, kw in variants:
+                fp = make()
+                sh = ShardedEngine(kind, fp, opts, **kw)
+                st, stats, msg = sh.run(cap, poll_interval=8) if not sh.colshard else sh.run(cap)
+                sh.read_point()
+                info = sh.eng.shard_info() if sh.colshard else {}
+                xname = sh.exchange_name
+                sh.close()
+                out[name + "/" + vname] = dict(
+                    same_status=(st == st_ref), status=int(st), iters=int(stats.iters), iters_ref=int(stats_ref.iters),
+                    expect=(int(st_ref) if cap < 100000 else E.OPTIMAL),
+                    same_B=bool(np.array_equal(fp.B, ref_fp.B)), same_N=bool(np.array_equal(fp.N, ref_fp.N)),
+                    # same pivots; x to rounding: the two drivers may refresh B^-1 (and with it x_B) at different
+                    # moments, e.g. inside a batch that a maintenance request has voided
+                    same_x=bool(np.allclose(fp.x, ref_fp.x, rtol=0, atol=1e-10 * (1 + np.abs(ref_fp.x).max()))), msg=msg,
+                    info=info, exchange=xname)
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -106,7 +117,7 @@ def test_sharded_engine_takes_the_same_pivots_world2():
         p.daemon = True
         p.start()
     try:
-        results = [q.get(timeout=150) for _ in range(world)]
+        results = [q.get(timeout=400) for _ in range(world)]
     except Exception:
         for p in procs:
             if p.is_alive():
@@ -117,11 +128,20 @@ def test_sharded_engine_takes_the_same_pivots_world2():
         if p.is_alive():
             p.kill()
         assert p.exitcode == 0
+    full = cols = 0
     for rank, out in results:
         for name, r in out.items():
             assert r["same_status"] and r["status"] == r["expect"], (rank, name, r)
             assert r["iters"] == r["iters_ref"], (rank, name, r)
             assert r["same_B"] and r["same_N"] and r["same_x"], (rank, name, r)
+            if "colshard" in name:
+                lo, hi = r["info"]["own"]
+                assert hi > lo or rank > 0, (rank, name, r["info"])
+                assert r["info"]["transport"] == ("mailbox" if name.endswith("mailbox") else "callback"), (name, r["info"])
+                full += r["info"]["full_exchanges"]
+                cols += r["info"]["column_requests"]
+    # the degenerate random LPs must have driven the loop through its fall-back (ties below the gap) too
+    assert full > 0, (full, cols)
 
 
 def test_stepped_api_world1_matches_run():
