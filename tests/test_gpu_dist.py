@@ -24,6 +24,23 @@ def _flat(seed, m, n):
                          f["x"], f["B"], f["N"], f["Nb"])
 
 
+def _tied_flat():
+    """primal phase 1 of a synthetic LP whose structural columns come in identical triples: the
+    reduced costs tie EXACTLY, three at a time, across the two ranks' blocks — more candidates than
+    a pack holds, and a winner picked by N.index that is usually in nobody's pack: the sharded loop
+    has to fall back to the full exchange and to ship the column on request"""
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(3, 40, 90)
+    m, n = f["m"], f["n"]
+    A = f["A"].reshape(n, m).copy()      # column j = A[j]
+    for j in range(30):
+        A[j + 30] = A[j]
+        A[j + 60] = A[j]
+    return E.FlatProblem(f["m"], f["n"], f["n_c"], A.reshape(-1), f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                         f["x"], f["B"], f["N"], f["Nb"])
+
+
 def _dual_flat():
     """dual phase-1 arrays of a small synthetic LP, built by the oracle's setup (test input)."""
     from ellp_amd import _engine as E
@@ -65,7 +82,8 @@ def _worker(rank, world, port, q):
         # per pricing block) with block0 != 0 on rank 1; it is stopped after 250 iterations
         cases = [("primal", E.ENGINE_PRIMAL, lambda: _flat(20260301, 50, 120), 100000),
                  ("dual", E.ENGINE_DUAL, _dual_flat, 100000),
-                 ("primal-wave", E.ENGINE_PRIMAL, lambda: _flat(7, 600, 5000), 250)]
+                 ("primal-wave", E.ENGINE_PRIMAL, lambda: _flat(7, 600, 5000), 250),
+                 ("primal-ties", E.ENGINE_PRIMAL, _tied_flat, 100000)]
         # random wide LPs of every bound kind (several columns per pricing block, bound flips, Fixed /
         # TwoSided entering variables), first 150 pivots of primal and dual phase 1
         for seed in (300, 305, 311):
@@ -141,7 +159,7 @@ def test_sharded_engine_takes_the_same_pivots_world2():
                 full += r["info"]["full_exchanges"]
                 cols += r["info"]["column_requests"]
     # the degenerate random LPs must have driven the loop through its fall-back (ties below the gap) too
-    assert full > 0, (full, cols)
+    assert full > 0 and cols > 0, (full, cols)
 
 
 def test_stepped_api_world1_matches_run():
