@@ -4047,6 +4047,11 @@ ellp_status ellp_engine_mailbox_selftest(ellp_engine *e, int rounds, char *errbu
         HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         if (e->h_st->status != ST_RUNNING) {
+            // re-arm: the engine is still good, only this transport is not
+            const int32_t running = ST_RUNNING;
+            (void)hipMemcpy(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice);
+            e->h_st->status = ST_RUNNING;
+            e->transport = 0;
             set_err(errbuf, errlen, "mailbox self-test: a wait timed out (round %d)", round);
             return ELLP_ERR_DEVICE;
         }
@@ -4054,6 +4059,7 @@ ellp_status ellp_engine_mailbox_selftest(ellp_engine *e, int rounds, char *errbu
             for (int64_t i = 0; i < n; ++i) {
                 const double want = (double)(r * 1000003 + round * 7919) + (double)i * 0.5;
                 if (all[(size_t)(r * n + i)] != want) {
+                    e->transport = 0;
                     set_err(errbuf, errlen, "mailbox self-test: word %lld of rank %d's segment is wrong in round %d", (long long)i, r, round);
                     return ELLP_ERR_DEVICE;
                 }
