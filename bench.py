@@ -182,12 +182,12 @@ def pmc_traffic(m, n, solver, dual):
         mode = "1" if dual else "0"
         for kname, kv in pm["kernels"].items():
             hit = False
-            for prefix in ("k_price_wave<", "k_price2_wave<"):
-                if kname.startswith(prefix):
-                    hit = kname[len(prefix):].rstrip(">").strip() == mode
-            for prefix in ("k_price<", "k_price2<"):
-                if kname.startswith(prefix):
-                    hit = kname.split(",")[1].strip().rstrip(">") == mode
+            if kname == "k_price2_wave" or kname.startswith("k_price2<"):  # two-launch pipeline: primal only
+                hit = not dual
+            elif kname.startswith("k_price_wave<"):
+                hit = kname[len("k_price_wave<"):].rstrip(">").strip() == mode
+            elif kname.startswith("k_price<"):
+                hit = kname.split(",")[1].strip().rstrip(">") == mode
             if hit:
                 return kv["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
     return None, None
