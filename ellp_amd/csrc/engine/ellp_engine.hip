@@ -2201,6 +2201,7 @@ struct ellp_engine {
     uint64_t resyncs = 0;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
+    int32_t *binfo = nullptr;
     double *aq_save = nullptr, *bmin = nullptr;  // two-launch pipeline: parked entering column, row-block minima of lambda
     bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
     bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
@@ -2632,7 +2633,7 @@ void launch_price2(ellp_engine *e, int use_pend) {
     a.p.N_index = e->N_index; a.p.dd = nullptr; a.p.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.p.st = e->st;
     a.p.ld = e->ld; a.p.nN = e->nN; a.p.cpb = e->cpb; a.p.block0 = e->rank * e->nbs; a.p.eps = e->eps;
     a.u0 = e->u; a.u1 = e->u + e->ld; a.W0 = e->W; a.W1 = e->W2;
-    a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bidx = e->bidx; a.dpos = e->dpos;
+    a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bsec = e->bmin + e->m; a.bidx = e->bidx; a.binfo = e->binfo; a.dpos = e->dpos;
     a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.m = e->m; a.rpb = e->upd2_rows; a.use_pend = use_pend; a.ill_tol = e->ill_tol;
@@ -2668,7 +2669,8 @@ void launch_ftran_eta(ellp_engine *e) {
     FtranEtaArgs a{};
     a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
     a.N_index = e->N_index; a.B_index = e->B_index; a.Nb = e->Nb; a.kind = e->kindv;
-    a.x = e->x; a.lb = e->lb; a.ub = e->ub; a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bidx = e->bidx; a.dpos = e->dpos;
+    a.x = e->x; a.lb = e->lb; a.ub = e->ub; a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bsec = e->bmin + e->m; a.bidx = e->bidx;
+    a.binfo = e->binfo; a.dpos = e->dpos;
     a.A_B = e->A_B; a.c_B = e->c_B; a.aq_save = e->aq_save; a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
     a.nblocks = e->nblocks; a.cpb = e->cpb; a.rows_per_block = e->upd2_rows; a.eps = e->eps;
     const dim3 g(e->upd2_blocks + 1), b(256);
@@ -3043,7 +3045,8 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->c_N, (size_t)nNa));
     ECHK(dmalloc(e, &e->u, (size_t)(2 * ld)));  // two buffers (DevState::usel): the two-launch pipeline reads one, writes the other
     ECHK(dmalloc(e, &e->aq_save, (size_t)ld));
-    ECHK(dmalloc(e, &e->bmin, (size_t)m));
+    ECHK(dmalloc(e, &e->bmin, (size_t)(2 * m)));  // smallest | second smallest per row block
+    ECHK(dmalloc(e, &e->binfo, (size_t)m));
     e->nbs = e->nblocks;
     e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     ECHK(dmalloc(e, &e->X, (size_t)e->seg));
