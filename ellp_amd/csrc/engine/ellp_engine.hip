@@ -152,27 +152,24 @@ __device__ __forceinline__ double wave_min(double v) {
 // ------------------------------------------------------------------ pricing output / exchange buffer
 // The pricing kernels write their per-column and per-block results into ONE buffer laid out in
 // `world` equal segments, one per rank (world = 1 on a single GPU):
-//   segment s = [ blockkey (nbs) | blockpos (nbs, stored as f64) | blocksecond (nbs) | key (nbs*cpb) | r (nbs*cpb) ]
-// (blockpos: dual = position of the block's first minimum; primal, two-launch pipeline = position of its
-//  maximal key; blocksecond: primal, two-launch pipeline = the block's second largest key)
+//   segment s = [ blockkey (nbs) | blockpos (nbs, stored as f64) | key (nbs*cpb) | r (nbs*cpb) ]
 // where rank s prices the blocks [s*nbs, (s+1)*nbs), i.e. nonbasic positions
 // [s*nbs*cpb, (s+1)*nbs*cpb).  With column-block sharding each rank fills its own
 // segment and ONE all-gather of the buffer per iteration gives every rank the complete
 // pricing result; everything downstream is replicated and deterministic.
 struct Xchg {
     double *X;
-    int64_t seg;  // doubles per segment = 3*nbs + 2*nbs*cpb
+    int64_t seg;  // doubles per segment = 2*nbs + 2*nbs*cpb
     int nbs, cpb;
     __device__ __forceinline__ double &bk(int b) const { return X[(int64_t)(b / nbs) * seg + (b % nbs)]; }
     __device__ __forceinline__ double &bp(int b) const { return X[(int64_t)(b / nbs) * seg + nbs + (b % nbs)]; }
-    __device__ __forceinline__ double &b2(int b) const { return X[(int64_t)(b / nbs) * seg + 2 * nbs + (b % nbs)]; }
     __device__ __forceinline__ double &key(int64_t j) const {
         const int64_t per = (int64_t)nbs * cpb, s = j / per;
-        return X[s * seg + 3 * nbs + (j - s * per)];
+        return X[s * seg + 2 * nbs + (j - s * per)];
     }
     __device__ __forceinline__ double &r(int64_t j) const {
         const int64_t per = (int64_t)nbs * cpb, s = j / per;
-        return X[s * seg + 3 * nbs + per + (j - s * per)];
+        return X[s * seg + 2 * nbs + per + (j - s * per)];
     }
 };
 
@@ -2207,8 +2204,6 @@ struct ellp_engine {
     int32_t *binfo = nullptr;
     double *aq_save = nullptr, *bmin = nullptr;  // two-launch pipeline: parked entering column, row-block minima of lambda
     bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
-    int ftran_sched = -1;   // k_ftran_eta's SCHED (-1: by size); ELLP_FTRAN_SCHED overrides (measurements)
-    bool ftran_stream = false;  // k_ftran_eta<0, 0>: no rows held in registers across the fold
     bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
     size_t price2_lds = 0;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
@@ -2679,21 +2674,12 @@ void launch_ftran_eta(ellp_engine *e) {
     a.A_B = e->A_B; a.c_B = e->c_B; a.aq_save = e->aq_save; a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
     a.nblocks = e->nblocks; a.cpb = e->cpb; a.rows_per_block = e->upd2_rows; a.eps = e->eps;
     const dim3 g(e->upd2_blocks + 1), b(256);
-    int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
-    if (e->ftran_stream) nr = 99;              // all rows streamed after the fold (k_ftran_eta<0, 0>)
-    const int sched = e->ftran_sched >= 0 ? e->ftran_sched : (nr > 4 ? 1 : 0);
-#define ELLP_FE(NR_)                                                                                        \
-    do {                                                                                                    \
-        if (sched == 2) hipLaunchKernelGGL((k_ftran_eta<NR_, 2>), g, b, e->ftran_lds, e->stream, a);        \
-        else if (sched == 1) hipLaunchKernelGGL((k_ftran_eta<NR_, 1>), g, b, e->ftran_lds, e->stream, a);   \
-        else hipLaunchKernelGGL((k_ftran_eta<NR_, 0>), g, b, e->ftran_lds, e->stream, a);                   \
-    } while (0)
-    if (nr <= 1) ELLP_FE(1);
-    else if (nr <= 2) ELLP_FE(2);
-    else if (nr <= 4) ELLP_FE(4);
-    else if (nr <= 8) ELLP_FE(8);
-    else hipLaunchKernelGGL((k_ftran_eta<0, 0>), g, b, e->ftran_lds, e->stream, a);
-#undef ELLP_FE
+    const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
+    if (nr <= 1) hipLaunchKernelGGL((k_ftran_eta<1>), g, b, e->ftran_lds, e->stream, a);
+    else if (nr <= 2) hipLaunchKernelGGL((k_ftran_eta<2>), g, b, e->ftran_lds, e->stream, a);
+    else if (nr <= 4) hipLaunchKernelGGL((k_ftran_eta<4>), g, b, e->ftran_lds, e->stream, a);
+    else if (nr <= 8) hipLaunchKernelGGL((k_ftran_eta<8>), g, b, e->ftran_lds, e->stream, a);
+    else hipLaunchKernelGGL((k_ftran_eta<0>), g, b, e->ftran_lds, e->stream, a);
 }
 
 // iteration k of the two-launch pipeline: P_k folds and books iteration k-1 (if one is open), prices k;
@@ -3062,7 +3048,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->bmin, (size_t)(2 * m)));  // smallest | second smallest per row block
     ECHK(dmalloc(e, &e->binfo, (size_t)m));
     e->nbs = e->nblocks;
-    e->seg = 3 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
+    e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     ECHK(dmalloc(e, &e->X, (size_t)e->seg));
     ECHK(dmalloc(e, &e->x, (size_t)n_c));
     ECHK(dmalloc(e, &e->lb, (size_t)n_c));
@@ -3205,15 +3191,6 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
                     (pl == 2 || (pl == 0 && m >= 1024));
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
-        if (const char *v = getenv("ELLP_FTRAN_SCHED"); v && v[0]) e->ftran_sched = atoi(v);
-        if (const char *v = getenv("ELLP_FTRAN_STREAM"); v && v[0]) e->ftran_stream = atoi(v) != 0;
-        if (const char *v = getenv("ELLP_FTRAN_ROWS"); v && v[0]) {  // rows per block of k_ftran_eta / k_update2 (measurements)
-            const int rr = atoi(v);
-            if (rr == 1 || rr == 2 || rr == 4 || rr == 8) {
-                e->upd2_rows = rr;
-                e->upd2_blocks = (int)((m + rr - 1) / rr);
-            }
-        }
     }
     // initial B^-1 (k_small keeps none: its LU is redone every iteration, with the reference's guard)
     if (e->small) e->w_valid = false;
@@ -3265,8 +3242,8 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
         SmallArgs a{};
         a.A_B = e->A_B; a.A_N = e->A_N; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
         a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
-        a.kbuf = e->X + 3 * e->nbs;
-        a.rbuf = e->X + 3 * e->nbs + per;
+        a.kbuf = e->X + 2 * e->nbs;
+        a.rbuf = e->X + 2 * e->nbs + per;
         a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
         a.max_iters = remaining < 16384 ? remaining : 16384;
         a.nch = (int)((e->nN + 63) / 64);
@@ -3469,13 +3446,13 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
     case ELLP_TAP_R:
     case ELLP_TAP_ALPHA:
         if (e->world != 1) return ELLP_ERR_ARG;
-        src = e->X + 3 * e->nbs + (int64_t)e->nbs * e->cpb;
+        src = e->X + 2 * e->nbs + (int64_t)e->nbs * e->cpb;
         count = e->nN;
         break;
     case ELLP_TAP_D: src = e->d; count = e->m; break;
     case ELLP_TAP_KEY:
         if (e->world != 1) return ELLP_ERR_ARG;
-        src = e->X + 3 * e->nbs;
+        src = e->X + 2 * e->nbs;
         count = e->nN;
         break;
     case ELLP_TAP_STATE: {
@@ -3586,7 +3563,7 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
     e->rank = rank;
     e->world = world;
     e->nbs = (e->nblocks + world - 1) / world;
-    e->seg = 3 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
+    e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     double *nx = static_cast<double *>(exchange_buffer);  // caller-owned (e.g. a torch tensor) ...
     if (!nx) HIPCHK(dmalloc(e, &nx, (size_t)(e->seg * world)));  // ... or ours (released with the engine)
     HIPCHK(hipMemset(nx, 0, sizeof(double) * (size_t)(e->seg * world)));
@@ -3597,7 +3574,7 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
 int64_t ellp_engine_segment_doubles(ellp_engine *e, int world) {
     if (!e || world < 1) return ELLP_ERR_ARG;
     const int64_t nbs = (e->nblocks + world - 1) / world;
-    return 3 * nbs + 2 * nbs * e->cpb;
+    return 2 * nbs + 2 * nbs * e->cpb;
 }
 
 ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_doubles, int *rank, int *world) {
