@@ -311,9 +311,10 @@ class Engine:
 
     def counters(self):
         """host-side maintenance counters (TAP_STATE tail)"""
-        v = self.tap(TAP_STATE, 20)
+        v = self.tap(TAP_STATE, 22)
         return dict(drift=v[12], drift_checks=int(v[13]), maint_requests=int(v[14]), refreshes=int(v[15]),
-                    rebuilds=int(v[16]), resyncs=int(v[17]), last_refresh_residual=v[18], launches_per_iteration=int(v[19]))
+                    rebuilds=int(v[16]), resyncs=int(v[17]), last_refresh_residual=v[18], launches_per_iteration=int(v[19]),
+                    rebuild_shortcuts=int(v[20]), t_setup_s=float(v[21]))
 
     # ---- sharded / stepped driving (see ellp_amd/dist.py)
     def segment_doubles(self, world):

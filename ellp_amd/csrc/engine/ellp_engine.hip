@@ -2171,6 +2171,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
 
 #include "ellp_lagged.inc"
 #include "ellp_shard.inc"
+#include "ellp_rebuild.inc"
 #include "ellp_small.inc"
 
 }  // namespace
@@ -2202,6 +2203,12 @@ struct ellp_engine {
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
     int32_t *binfo = nullptr;
+    // blocked rebuild (ellp_rebuild.inc)
+    double *bl_Cpart = nullptr, *bl_C = nullptr, *bl_V = nullptr, *bl_Vs = nullptr, *bl_Wp = nullptr, *bl_nzval = nullptr;
+    int64_t *bl_Pm = nullptr, *bl_nzrow = nullptr;
+    int32_t *bl_nzcnt = nullptr;
+    int bl_splits = 1;
+    uint64_t rebuild_shortcuts = 0;
     double *aq_save = nullptr, *bmin = nullptr;  // two-launch pipeline: parked entering column, row-block minima of lambda
     bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
     bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
@@ -2467,7 +2474,7 @@ void launch_btran(ellp_engine *e) {
     hipLaunchKernelGGL(k_btran_reduce, dim3((unsigned)((e->ld + 255) / 256)), dim3(256), 0, e->stream, a);
 }
 
-void launch_refactor(ellp_engine *e) {
+void launch_refactor_columnwise(ellp_engine *e) {
     Prof p(e, ELLP_K_REFACTOR);
     RefArgs a{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows,
               e->kind == ELLP_ENGINE_PRIMAL ? e->eps : 0.0};
@@ -2483,6 +2490,68 @@ void launch_refactor(ellp_engine *e) {
     e->refactors += 1;
     e->since_refactor = 0;
     e->u_valid = false;
+}
+
+// Blocked rebuild (ellp_rebuild.inc).  One host synchronisation: after the probe for a generalised
+// permutation matrix (the artificial / slack bases every phase 1 starts from), to know whether the
+// general elimination has to be enqueued at all.  Rebuilds are rare (engine creation, a refused refresh).
+void launch_refactor(ellp_engine *e) {
+    const bool legacy = e->bl_Cpart == nullptr || (getenv("ELLP_REBUILD") && !strcmp(getenv("ELLP_REBUILD"), "columnwise"));
+    if (legacy) {
+        launch_refactor_columnwise(e);
+        return;
+    }
+    Prof p(e, ELLP_K_REFACTOR);
+    const int64_t m = e->m;
+    BlArgs a{};
+    a.W0 = e->W; a.W1 = e->W2; a.A_B = e->A_B; a.Cpart = e->bl_Cpart; a.C0 = e->bl_C; a.C1 = e->bl_C + m * BL_NB;
+    a.V0 = e->bl_V; a.V1 = e->bl_V + m * BL_NB; a.Vs = e->bl_Vs; a.Wp = e->bl_Wp; a.used = e->used; a.perm = e->perm;
+    a.Pm = e->bl_Pm; a.st = e->st; a.m = m; a.ld = e->ld; a.splits = e->bl_splits;
+    a.ksplit = (int)round_up((m + e->bl_splits - 1) / e->bl_splits, 16);
+    a.eps = e->kind == ELLP_ENGINE_PRIMAL ? e->eps : 0.0;
+    e->refactors += 1;
+    e->since_refactor = 0;
+    e->u_valid = false;
+    // ---- shortcut: one nonzero per column, distinct rows
+    hipLaunchKernelGGL(k_bl_probe, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, e->stream, a, e->bl_nzval, e->bl_nzrow, e->bl_nzcnt);
+    hipLaunchKernelGGL(k_bl_perm_check, dim3(1), dim3(1024), 0, e->stream, a, e->bl_nzval, e->bl_nzrow, e->bl_nzcnt);
+    hipLaunchKernelGGL(k_bl_perm_fill, dim3((unsigned)m), dim3(256), 0, e->stream, a, e->bl_nzval, e->bl_nzrow);
+    DevState probe;
+    if (hipMemcpyAsync(&probe, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+        return;
+    const int32_t zero = 0;
+    (void)hipMemcpyAsync(&e->st->do_update, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    if (probe.status != ST_RUNNING) return;  // singular (or the engine is not running: the kernels did nothing)
+    if (probe.do_update) {
+        e->rebuild_shortcuts += 1;
+        return;
+    }
+    // ---- general case
+    RefArgs ra{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows, a.eps};
+    hipLaunchKernelGGL(k_ref_init, dim3(1024), dim3(256), 0, e->stream, ra);
+    const int nbw_max = m <= 2048 ? 16 : (m <= 4096 ? 8 : 4);
+    for (int64_t k0 = 0; k0 < m; k0 += BL_NB) {
+        a.k0 = (int)k0;
+        a.nbc = (int)((m - k0) < BL_NB ? (m - k0) : BL_NB);
+        a.sel = 0;
+        hipLaunchKernelGGL(k_bl_gemm1, dim3((unsigned)((m + 63) / 64), (unsigned)a.splits), dim3(256), 0, e->stream, a);
+        hipLaunchKernelGGL(k_bl_sum, dim3(256), dim3(256), 0, e->stream, a);
+        for (int j0 = 0; j0 < a.nbc; j0 += nbw_max) {
+            a.j0 = j0;
+            a.nbw = (a.nbc - j0) < nbw_max ? (a.nbc - j0) : nbw_max;
+            a.nacc = j0;
+            if (nbw_max == 16) hipLaunchKernelGGL((k_bl_factor<16, 2>), dim3(1), dim3(1024), 0, e->stream, a);
+            else if (nbw_max == 8) hipLaunchKernelGGL((k_bl_factor<8, 4>), dim3(1), dim3(1024), 0, e->stream, a);
+            else hipLaunchKernelGGL((k_bl_factor<4, 8>), dim3(1), dim3(1024), 0, e->stream, a);
+            hipLaunchKernelGGL(k_bl_apply, dim3((unsigned)((m + 7) / 8)), dim3(256), 0, e->stream, a);
+            a.sel ^= 1;
+        }
+        hipLaunchKernelGGL(k_bl_gather, dim3((unsigned)a.nbc), dim3(256), 0, e->stream, a);
+        hipLaunchKernelGGL(k_bl_gemm2, dim3((unsigned)((e->ld + 127) / 128), (unsigned)((m + 63) / 64)), dim3(256), 0, e->stream, a);
+    }
+    hipLaunchKernelGGL(k_ref_permute, dim3((unsigned)e->m), dim3(256), 0, e->stream, ra);
+    hipLaunchKernelGGL(k_ref_finish, dim3(1), dim3(1), 0, e->stream, ra);
 }
 
 // One Newton-Schulz step on the current inverse, enqueued without any host synchronisation: the
@@ -3047,6 +3116,20 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->aq_save, (size_t)ld));
     ECHK(dmalloc(e, &e->bmin, (size_t)(2 * m)));  // smallest | second smallest per row block
     ECHK(dmalloc(e, &e->binfo, (size_t)m));
+    if (m <= 8192) {  // blocked rebuild (k_bl_factor keeps m / 1024 rows per thread)
+        const int64_t nrb64 = (m + 63) / 64;
+        int sp = (int)((256 + nrb64 - 1) / nrb64);
+        e->bl_splits = sp < 1 ? 1 : (sp > 8 ? 8 : sp);
+        ECHK(dmalloc(e, &e->bl_Cpart, (size_t)(e->bl_splits * m * BL_NB)));
+        ECHK(dmalloc(e, &e->bl_C, (size_t)(2 * m * BL_NB)));
+        ECHK(dmalloc(e, &e->bl_V, (size_t)(2 * m * BL_NB)));
+        ECHK(dmalloc(e, &e->bl_Vs, (size_t)(m * 16)));
+        ECHK(dmalloc(e, &e->bl_Wp, (size_t)(BL_NB * ld)));
+        ECHK(dmalloc(e, &e->bl_Pm, (size_t)BL_NB));
+        ECHK(dmalloc(e, &e->bl_nzval, (size_t)m));
+        ECHK(dmalloc(e, &e->bl_nzrow, (size_t)m));
+        ECHK(dmalloc(e, &e->bl_nzcnt, (size_t)m));
+    }
     e->nbs = e->nblocks;
     e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     ECHK(dmalloc(e, &e->X, (size_t)e->seg));

@@ -266,7 +266,8 @@ enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_T
        ELLP_TAP_ALPHA = 5, ELLP_TAP_STATE = 6 /* 12 doubles: status,cur,s_q,s_r,theta_d,delta,lr,ldelta,iters,pivots,lambda,rq;
                                                   cap >= 14: + drift, drift checks; cap >= 20: + maintenance requests
                                                   serviced, Newton-Schulz refreshes, rebuilds, x_B resyncs, last
-                                                  refresh residual, launches per primal iteration */ };
+                                                  refresh residual, launches per primal iteration;
+                                                  cap >= 22: + rebuilds settled by the permutation shortcut, setup seconds */ };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
 /* One Newton-Schulz step W <- W + W (I - A_B W) on the resident inverse (two f64 GEMMs); this
