@@ -2520,7 +2520,7 @@ void launch_refactor(ellp_engine *e) {
     if (hipMemcpyAsync(&probe, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess)
         return;
-    const int32_t zero = 0;
+    static const int32_t zero = 0;  // static: the copy may still be in flight when this function returns
     (void)hipMemcpyAsync(&e->st->do_update, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     if (probe.status != ST_RUNNING) return;  // singular (or the engine is not running: the kernels did nothing)
     if (probe.do_update) {
@@ -2530,7 +2530,12 @@ void launch_refactor(ellp_engine *e) {
     // ---- general case
     RefArgs ra{e->W, e->W2, e->d, e->A_B, e->used, e->perm, e->st, e->m, e->ld, e->upd_rows, a.eps};
     hipLaunchKernelGGL(k_ref_init, dim3(1024), dim3(256), 0, e->stream, ra);
-    const int nbw_max = m <= 2048 ? 16 : (m <= 4096 ? 8 : 4);
+    const int bl_nt = (getenv("ELLP_BL_NT") && atoi(getenv("ELLP_BL_NT")) == 1024) ? 1024 : 512;
+    int nbw_max = m <= 2048 ? 16 : (m <= 4096 ? 8 : 4);
+    if (const char *v = getenv("ELLP_BL_NBW"); v && v[0]) {  // tests: a narrower sub-panel than the size needs
+        const int w = atoi(v);
+        if ((w == 8 || w == 4) && w < nbw_max) nbw_max = w;
+    }
     for (int64_t k0 = 0; k0 < m; k0 += BL_NB) {
         a.k0 = (int)k0;
         a.nbc = (int)((m - k0) < BL_NB ? (m - k0) : BL_NB);
@@ -2541,9 +2546,15 @@ void launch_refactor(ellp_engine *e) {
             a.j0 = j0;
             a.nbw = (a.nbc - j0) < nbw_max ? (a.nbc - j0) : nbw_max;
             a.nacc = j0;
-            if (nbw_max == 16) hipLaunchKernelGGL((k_bl_factor<16, 2>), dim3(1), dim3(1024), 0, e->stream, a);
-            else if (nbw_max == 8) hipLaunchKernelGGL((k_bl_factor<8, 4>), dim3(1), dim3(1024), 0, e->stream, a);
-            else hipLaunchKernelGGL((k_bl_factor<4, 8>), dim3(1), dim3(1024), 0, e->stream, a);
+            if (bl_nt == 512) {  // two waves per SIMD, 256 VGPRs each: 4 / 8 / 16 rows per thread
+                if (nbw_max == 16) hipLaunchKernelGGL((k_bl_factor<16, 4, 512>), dim3(1), dim3(512), 0, e->stream, a);
+                else if (nbw_max == 8) hipLaunchKernelGGL((k_bl_factor<8, 8, 512>), dim3(1), dim3(512), 0, e->stream, a);
+                else hipLaunchKernelGGL((k_bl_factor<4, 16, 512>), dim3(1), dim3(512), 0, e->stream, a);
+            } else {
+                if (nbw_max == 16) hipLaunchKernelGGL((k_bl_factor<16, 2, 1024>), dim3(1), dim3(1024), 0, e->stream, a);
+                else if (nbw_max == 8) hipLaunchKernelGGL((k_bl_factor<8, 4, 1024>), dim3(1), dim3(1024), 0, e->stream, a);
+                else hipLaunchKernelGGL((k_bl_factor<4, 8, 1024>), dim3(1), dim3(1024), 0, e->stream, a);
+            }
             hipLaunchKernelGGL(k_bl_apply, dim3((unsigned)((m + 7) / 8)), dim3(256), 0, e->stream, a);
             a.sel ^= 1;
         }
@@ -3284,6 +3295,9 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     prof_collect(e);
     if (e->h_st->status != ST_RUNNING) {
         ellp_status s = status_message(*e->h_st, errbuf, errlen);
+        if (getenv("ELLP_DEBUG"))
+            fprintf(stderr, "ellp: initial rebuild failed: status %d, column %lld, pivot row %lld, |pivot| %.3e\n", (int)s,
+                    (long long)e->h_st->refk, (long long)e->h_st->r, e->h_st->d_r);
         ellp_engine_destroy(e);
         return s;
     }
@@ -3557,6 +3571,11 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                 dst[17] = (double)e->resyncs;
                 dst[18] = h.resid;
                 dst[19] = e->small ? 0.0 : (e->lagged ? 2.0 : 3.0);  // 0: whole iterations inside one persistent launch
+                if (cap >= 22) {
+                    dst[20] = (double)e->rebuild_shortcuts;
+                    dst[21] = e->t_setup;
+                    return 22;
+                }
                 return 20;
             }
             return 14;
@@ -4166,7 +4185,7 @@ static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats
     const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 32;
     int64_t period = e->refactor_period > 0 ? e->refactor_period : default_period(e);
     auto rearm = [&]() {
-        const int32_t running = ST_RUNNING;
+        static const int32_t running = ST_RUNNING;  // static: the copy is asynchronous
         (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
         e->h_st->status = ST_RUNNING;
     };
