@@ -8,6 +8,9 @@
  * Build with -ffp-contract=off: Rust never contracts a*b+c into an FMA.
  */
 #include "ellp_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include <math.h>
 #include <stdio.h>
@@ -61,6 +64,15 @@ static void set_err(char *err, size_t errlen, const char *msg) {
  * CPU baseline pays the reference's full (2/3) m^3 per iteration. */
 static int g_dense_lu = 0;
 void eo_set_dense_lu(int on) { g_dense_lu = on; }
+
+/* Threads for the ONCE-PER-SOLVE setup factorizations (the rank check's QR, the LU of A^T that picks
+ * the dual phase-1 basis) when a test builds phase arrays at BASELINE.json's full sizes (2 x 56 GFLOP of
+ * QR at config 3).  Only loops over independent columns are shared out and every column is still
+ * processed by one thread in the sequential order, so every number is bit for bit the one-thread
+ * result.  1 (the default) everywhere else — in particular for the timed CPU baseline of bench.py, which
+ * is the reference's single-threaded algorithm. */
+static int g_setup_threads = 1;
+void eo_set_setup_threads(int n) { g_setup_threads = n > 1 ? n : 1; }
 
 static eo_trace_fn g_trace = NULL;
 static void *g_trace_user = NULL;
@@ -159,6 +171,7 @@ static void lu_factor_inplace(lu_t *f) {
         if (piv != i) {
             perm_push(&f->p, i, piv);
             /* swap rows i, piv in columns [0, i) and in column i .. nc (gauss_step_swap) */
+#pragma omp parallel for if (g_setup_threads > 1 && nc > 256) num_threads(g_setup_threads) schedule(static)
             for (int64_t k = 0; k < nc; ++k) {
                 double *ck = M + k * nr;
                 double t = ck[i];
@@ -168,6 +181,7 @@ static void lu_factor_inplace(lu_t *f) {
         }
         double inv_diag = 1.0 / diag;
         for (int64_t r = i + 1; r < nr; ++r) ci[r] *= inv_diag;
+#pragma omp parallel for if (g_setup_threads > 1 && nc - i > 64) num_threads(g_setup_threads) schedule(static)
         for (int64_t k = i + 1; k < nc; ++k) {
             double *ck = M + k * nr;
             double a = -ck[i];
@@ -461,6 +475,46 @@ static void col_piv_qr(double *M, int64_t nr, int64_t nc, perm_t *p, double *rdi
     for (int64_t i = 0; i < mn; ++i) {
         int64_t pj = i;
         double best = fabs(M[i + i * nr]);
+        if (g_setup_threads > 1 && (nc - i) * (nr - i) > 65536) {
+            /* the column-major scan with a strict '>' ends at the FIRST column that holds the maximum:
+             * per-thread (maximum, first column holding it) over contiguous column ranges, combined in
+             * thread order — the same column */
+            const int nt = g_setup_threads;
+            double tb[256];
+            int64_t tj[256];
+            const int ntc = nt < 256 ? nt : 256;
+#pragma omp parallel num_threads(ntc)
+            {
+#ifdef _OPENMP
+                const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+                const int t = 0, T = 1;
+#endif
+                const int64_t span = nc - i, lo = i + span * t / T, hi = i + span * (t + 1) / T;
+                double b = -1.0;
+                int64_t bj = -1;
+                for (int64_t j = lo; j < hi; ++j) {
+                    const double *cj = M + j * nr;
+                    for (int64_t r = i; r < nr; ++r) {
+                        double v = fabs(cj[r]);
+                        if (v > b) {
+                            b = v;
+                            bj = j;
+                        }
+                    }
+                }
+                tb[t] = b;
+                tj[t] = bj;
+#pragma omp single
+                { tb[255] = (double)T; }
+            }
+            const int T = (int)tb[255] < ntc ? (int)tb[255] : ntc;
+            for (int t = 0; t < T; ++t)
+                if (tj[t] >= 0 && tb[t] > best) {
+                    best = tb[t];
+                    pj = tj[t];
+                }
+        } else
         for (int64_t j = i; j < nc; ++j) {
             const double *cj = M + j * nr;
             for (int64_t r = i; r < nr; ++r) {
@@ -502,6 +556,7 @@ static void col_piv_qr(double *M, int64_t nr, int64_t nc, perm_t *p, double *rdi
             rdiag[i] = fabs(signed_norm);
             /* reflect the trailing columns: col -= 2 (v.col) v  (overall sign immaterial:
              * only |entries| steer later pivots and only |R_ii| is consumed) */
+#pragma omp parallel for if (g_setup_threads > 1 && (nc - i) * len > 65536) num_threads(g_setup_threads) schedule(static)
             for (int64_t j = i + 1; j < nc; ++j) {
                 double *cj = M + i + j * nr;
                 double dot = 0.0;
@@ -673,6 +728,7 @@ static void fplu_factor(fplu_t *f, const double *A, int64_t nr, int64_t nc) {
         double *ci = M + i * nr;
         double inv_diag = 1.0 / diag;
         for (int64_t r = i + 1; r < nr; ++r) ci[r] *= inv_diag;
+#pragma omp parallel for if (g_setup_threads > 1 && nc - i > 64) num_threads(g_setup_threads) schedule(static)
         for (int64_t k = i + 1; k < nc; ++k) {
             double *ck = M + k * nr;
             double a = -ck[i];
@@ -1203,9 +1259,6 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
  * the engine over windows of thousands of pivots at full size, where the LU-per-iteration loop
  * would take hours.  It is itself checked against the loop above (tests/test_oracle_binv.py).
  * refresh > 0: B^-1 is recomputed from an LU of A_B every `refresh` basis changes. */
-#ifdef _OPENMP
-#include <omp.h>
-#endif
 #include <time.h>
 
 static double now_seconds(void) {

@@ -155,6 +155,8 @@ void eo_set_trace(eo_trace_fn fn, void *user);
 /* 1: LU/solves do nalgebra's full dense work (no zero-multiplier skip) — used when the oracle
  * is TIMED as the CPU baseline; results are identical either way. */
 void eo_set_dense_lu(int on);
+/* threads for the once-per-solve setup factorizations (bitwise the one-thread results); default 1 */
+void eo_set_setup_threads(int n);
 
 typedef struct eo_result {
     int status;       /* EO_OPTIMAL.. or error */

@@ -109,6 +109,7 @@ def lib():
     L.eo_solve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(_Result)]
     L.eo_result_free.argtypes = [C.POINTER(_Result)]
     L.eo_set_dense_lu.argtypes = [C.c_int]
+    L.eo_set_setup_threads.argtypes = [C.c_int]
     L.eo_synth_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
     _lib = L
@@ -363,6 +364,12 @@ def solve(prob, solver="primal", max_iter=1000):
     out = Result(r)
     lib().eo_result_free(C.byref(r))
     return out
+
+
+def set_setup_threads(n):
+    """threads for the setup factorizations (QR of the rank check, LU of A^T): bitwise the one-thread
+    results (columns are shared out, each processed sequentially); 1 restores the default"""
+    lib().eo_set_setup_threads(int(n))
 
 
 def set_dense_lu(on):

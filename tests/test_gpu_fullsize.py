@@ -226,3 +226,69 @@ def test_c5_primal_window_parity():
     np.testing.assert_array_equal(fp.N, ov.N)
     np.testing.assert_array_equal(fp.Nb, ov.Nb)
     np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
+
+
+# ---- config 4 on the reference's OWN dual phase-1 arrays (dual_problem.rs:89-256) at full size: the box
+# problem of the config-3 LP (every variable TwoSided [0,1], rows `= 0`), basis from the LU of A^T,
+# nonbasics at lower / upper by the sign of d — built by the oracle's setup (its two rank-check QRs and
+# the LU share their independent columns out over the host cores, bit for bit the one-thread result).
+# The covering-LP windows above start from a slack basis with Lower labels only; these run the dual loop
+# with TwoSided basics leaving at either bound and Upper-labelled nonbasics entering, at m = 2000.
+@pytest.fixture(scope="module")
+def dual_phase1_c3():
+    eo.set_setup_threads(eo.host_threads())
+    try:
+        d1, err = eo.dual_phase1(eo.synth_problem(SEED, M, N_STRUCT))
+    finally:
+        eo.set_setup_threads(1)
+    assert d1 is not None and not err
+    v = d1.view()
+    assert v.m == M and v.nN == N_STRUCT
+    assert set(np.unique(v.kind)) == {3}                       # all TwoSided
+    nb = np.bincount(v.Nb[:v.nN], minlength=3)
+    assert nb[0] > 1000 and nb[1] > 1000                       # nonbasics at lower AND at upper
+    return v
+
+
+def _dflat(v):
+    from ellp_amd import _engine as E
+    return E.FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B, v.N[:v.nN], v.Nb[:v.nN], v.y, v.d)
+
+
+def test_c4_reference_dual_phase1_window_parity(dual_phase1_c3):
+    """40 pivots against the LU-per-iteration oracle (0.7 s per pivot at this size)"""
+    from ellp_amd import _engine as E
+    W = 40
+    v = dual_phase1_c3
+    ov = v.copy()
+    st_o, it_o, _ = eo.dual_solve_with_initial(ov, W)
+    fp = _dflat(v)
+    st_g, stats, msg = E.dual_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, msg
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N[:ov.nN])
+    np.testing.assert_array_equal(fp.Nb, ov.Nb[:ov.nN])
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-9 * (1 + np.abs(ov.x).max()))
+    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-9 * (1 + np.abs(ov.y).max()))
+    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-9 * (1 + np.abs(ov.d).max()))
+
+
+def test_c4_reference_dual_phase1_long_window_parity(dual_phase1_c3):
+    """1500 pivots against the explicit-B^-1 CPU dual loop (same rules, checked against the LU oracle in
+    tests/test_oracle_binv.py): same basis, same labels — leaving sides Lower and Upper both occur"""
+    from ellp_amd import _engine as E
+    W = 1500
+    v = dual_phase1_c3
+    ov = v.copy()
+    st_o, it_o, msg_o, _ = eo.dual_binv_solve_with_initial(ov, W)
+    fp = _dflat(v)
+    st_g, stats, msg = E.dual_solve_with_initial(fp, E.default_opts(max_iter=W))
+    assert st_g == st_o == E.MAXITER and stats.iters == it_o == W, (msg, msg_o)
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N, ov.N[:ov.nN])
+    np.testing.assert_array_equal(fp.Nb, ov.Nb[:ov.nN])
+    changed = fp.Nb != v.Nb[:v.nN]
+    assert changed.sum() > 50                                   # labels did move
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
+    np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-8 * (1 + np.abs(ov.d).max()))
+    np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-8 * (1 + np.abs(ov.y).max()))
