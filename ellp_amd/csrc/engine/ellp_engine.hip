@@ -1166,6 +1166,7 @@ struct Update2Args {
     double eps;
     const double *aq_cur;   // column-sharded engines: the entering column (A_N holds only positions [own0, own1))
     int64_t own0, own1;
+    int count_iter;         // 0: closing kernel of the two-launch pipeline (k_ftran_eta has counted the iteration)
 };
 
 // NR = double2 per thread per row (ceil(ld/512)); NR == 0: rows are streamed after the fold
@@ -1306,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         }
         if (isinf(lambda)) {  // primal…:404-406
             if (leader) {
-                st->iters += 1;
+                if (a.count_iter) st->iters += 1;
                 st->status = ELLP_UNBOUNDED;
             }
             return;
@@ -1468,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->lambda = lambda;
                 st->cur = cur ^ 1;
                 st->pivots += 1;
-                st->iters += 1;
+                if (a.count_iter) st->iters += 1;
                 if (tiny_pivot) st->tiny = 1;
             }
         } else if (tid == 0) {  // primal…:223-231
@@ -1481,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->status = ELLP_ERR_PANIC;
             }
             st->flips += 1;
-            st->iters += 1;
+            if (a.count_iter) st->iters += 1;
         }
     } else {
         // dual…:296-316
@@ -2456,6 +2457,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
+    a.count_iter = (MODE == 0 && e->lagged) ? 0 : 1;
     const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
@@ -2665,6 +2667,17 @@ void reconcile_counters(ellp_engine *e) {
     }
     e->enqueued = 0;
     e->iters_seen = e->h_st->iters;
+}
+
+// two-launch pipeline: k_ftran_eta reports the end of the solve in DevState::fin and leaves it to the next
+// kernel's leader to make it the status; after a drained read-back the host can do that itself
+void adopt_fin(ellp_engine *e) {
+    if (e->h_st->status != ST_RUNNING || !e->h_st->fin) return;
+    static int32_t fin_status;  // static: asynchronous copy
+    fin_status = e->h_st->fin - 1;
+    (void)hipMemcpyAsync(&e->st->status, &fin_status, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    (void)hipStreamSynchronize(e->stream);
+    e->h_st->status = fin_status;
 }
 
 // After a status read-back: if a kernel asked for maintenance, do it, re-arm the loop and report
@@ -3310,6 +3323,7 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
 // The explicit-inverse engine is about to be used on an engine that has been running k_small: build
 // B^-1 from the current A_B and leave the small path for good.
 static ellp_status ensure_inverse(ellp_engine *e, char *errbuf, size_t errlen) {
+    launch_flush(e);  // two-launch pipeline: B^-1 is complete only once the open iteration has been booked
     if (e->w_valid) {
         e->small = false;
         return ELLP_OPTIMAL;
@@ -3387,6 +3401,7 @@ ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
     e->w_valid = true;  // about to be
     e->small = false;
     e->need_dleave = true;
+    launch_flush(e);
     launch_refactor(e);
     HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -3425,6 +3440,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         reconcile_counters(e);
+        adopt_fin(e);
         if (e->h_st->status != ST_RUNNING) {
             result = status_message(*e->h_st, errbuf, errlen);
             remaining = 0;
@@ -3471,11 +3487,11 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                     if (to_launch == 0 && !pending[0] && !pending[1]) break;
                     slot ^= 1;
                 }
-                launch_flush(e);  // two-launch pipeline: fold and book the iteration that is still open
                 HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
                 HIPCHK(hipStreamSynchronize(e->stream));
                 HIPCHK(hipGetLastError());
                 reconcile_counters(e);
+                adopt_fin(e);
                 const uint64_t done = e->h_st->iters - iters0;
                 remaining = done < max_iters ? max_iters - done : 0;
                 if (service_maintenance_request(e)) continue;  // refreshed; the follow-up runs in the loop below
@@ -3489,12 +3505,12 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
                 else launch_dual_iteration(e);
             }
-            launch_flush(e);
             HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             HIPCHK(hipGetLastError());
             prof_collect(e);
             reconcile_counters(e);
+            adopt_fin(e);
             // iterations that really ran (a maintenance request voids the rest of its batch)
             const uint64_t done = e->h_st->iters - iters0;
             remaining = done < max_iters ? max_iters - done : 0;
@@ -3515,6 +3531,7 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, 
                                    double *y, double *d, char *errbuf, size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
+    launch_flush(e);  // two-launch pipeline: fold and book the iteration that is still open
     if (x) HIPCHK(hipMemcpyAsync(x, e->x, sizeof(double) * (size_t)e->n_c, hipMemcpyDeviceToHost, e->stream));
     if (B_index) HIPCHK(hipMemcpyAsync(B_index, e->B_index, sizeof(int64_t) * (size_t)e->m, hipMemcpyDeviceToHost, e->stream));
     if (N_index && e->nN) HIPCHK(hipMemcpyAsync(N_index, e->N_index, sizeof(int64_t) * (size_t)e->nN, hipMemcpyDeviceToHost, e->stream));
@@ -3530,6 +3547,7 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, 
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
     if (!e || !dst) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    if (what != ELLP_TAP_STATE) launch_flush(e);
     const double *src = nullptr;
     int64_t count = 0;
     switch (what) {
@@ -3793,6 +3811,7 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
             return ELLP_ERR_ARG;
         }
     HIPCHK(hipSetDevice(e->device));
+    launch_flush(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     double *c_dev = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c_dev), sizeof(double) * (size_t)e->n_c));
