@@ -103,6 +103,8 @@ struct DevState {
     int64_t pe_r;
     double pe_d_r, pe_alpha_r;
     int32_t usel_next;  // the u buffer that becomes current after k_ftran_eta
+    int32_t open;       // k_ftran_eta has entered (and counted) an iteration whose ratio test nobody has folded yet
+    int32_t pad_open;
     int32_t mv_pending;
     int64_t mv_r;       // deferred half of the column move: A_B[:, mv_r] <- aq_save, c_B[mv_r] <- cq_save
     double cq_save;
@@ -1469,6 +1471,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->lambda = lambda;
                 st->cur = cur ^ 1;
                 st->pivots += 1;
+                st->open = 0;
                 if (a.count_iter) st->iters += 1;
                 if (tiny_pivot) st->tiny = 1;
             }
@@ -1482,6 +1485,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->status = ELLP_ERR_PANIC;
             }
             st->flips += 1;
+            st->open = 0;
             if (a.count_iter) st->iters += 1;
         }
     } else {
@@ -2645,6 +2649,7 @@ void maintain_inverse(ellp_engine *e, bool reactive = false, bool rebuild = fals
     // two-launch pipeline: an open iteration (priced, FTRAN done, ratio test not folded) was decided with
     // the inverse that is about to be replaced — drop it; the next k_price2 starts afresh (use_pend = 0) and
     // the iteration is priced again from the maintained inverse.  Its eta-update half is already in B^-1.
+    if (e->lagged) hipLaunchKernelGGL(k_drop_open, dim3(1), dim3(1), 0, e->stream, e->st);
     e->lag_open = false;
     if (rebuild) launch_refactor(e);
     else launch_refresh(e);
@@ -3839,6 +3844,7 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     ns.tiny_p = 0;
     ns.fin = 0;
     ns.pe_valid = 0;
+    ns.open = 0;
     ns.mv_pending = 0;
     ns.need_rebuild = 0;
     ns.panic_code = 0;
