@@ -3510,6 +3510,9 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 if (e->kind == ELLP_ENGINE_PRIMAL) launch_primal_iteration(e);
                 else launch_dual_iteration(e);
             }
+            // this path serves the reactive maintenance of small LPs (and profiling): its follow-up refresh is
+            // meant to come AFTER the iteration that follows a tiny pivot, so that iteration is completed here
+            if (e->ill_tol > 0.0) launch_flush(e);
             HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             HIPCHK(hipGetLastError());
