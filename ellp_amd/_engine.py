@@ -27,7 +27,7 @@ class Opts(C.Structure):
     _fields_ = [("max_iter", C.c_uint64), ("eps", C.c_double), ("device", C.c_int32),
                 ("refactor_period", C.c_int32), ("btran_mode", C.c_int32),
                 ("poll_interval", C.c_int32), ("profile", C.c_int32), ("use_graph", C.c_int32),
-                ("pipeline", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("pipeline", C.c_int32), ("trace_len", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Stats(C.Structure):
@@ -95,6 +95,8 @@ def lib():
     L.ellp_engine_inverse_residual.restype = C.c_double
     L.ellp_engine_inverse_residual.argtypes = [C.c_void_p]
     L.ellp_engine_destroy.argtypes = [C.c_void_p]
+    L.ellp_engine_read_trace.restype = C.c_int64
+    L.ellp_engine_read_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.ellp_engine_request_maintenance.restype = C.c_int
     L.ellp_engine_request_maintenance.argtypes = [C.c_void_p]
     L.ellp_engine_debug_scale_inverse.restype = C.c_int
@@ -296,6 +298,15 @@ class Engine:
 
     def inverse_residual(self):
         return lib().ellp_engine_inverse_residual(self._h)
+
+    def read_trace(self, cap=1 << 16):
+        """(iterations, objectives) of the ring buffer kept with opts.trace_len > 0, oldest first"""
+        it = np.zeros(int(cap), dtype=np.uint64)
+        ob = np.zeros(int(cap), dtype=np.float64)
+        n = lib().ellp_engine_read_trace(self._h, _p(it), _p(ob), int(cap))
+        if n < 0:
+            raise EllpHipError(int(n), "read_trace failed")
+        return it[:n], ob[:n]
 
     def request_maintenance(self):
         """test hook: what a kernel does after a tiny pivot (the next run()/poll() services it)"""

@@ -134,6 +134,20 @@ struct DevState {
 #define STAMP(kern, slot) do { } while (0)
 #endif
 
+// optional objective trace (ellp_opts.trace_len): ring of (iteration, objective) pairs, written by whichever
+// leader completes an iteration
+struct Trace {
+    double *obj;
+    unsigned long long *it;
+    int len;
+};
+__device__ __forceinline__ void trace_put(const Trace &t, unsigned long long iters, double obj) {
+    if (t.len <= 0) return;
+    const int k = (int)(iters % (unsigned long long)t.len);
+    t.obj[k] = obj;
+    t.it[k] = iters;
+}
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -1169,6 +1183,7 @@ struct Update2Args {
     const double *aq_cur;   // column-sharded engines: the entering column (A_N holds only positions [own0, own1))
     int64_t own0, own1;
     int count_iter;         // 0: closing kernel of the two-launch pipeline (k_ftran_eta has counted the iteration)
+    Trace trace;
 };
 
 // NR = double2 per thread per row (ceil(ld/512)); NR == 0: rows are streamed after the fold
@@ -1473,6 +1488,8 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 st->pivots += 1;
                 st->open = 0;
                 if (a.count_iter) st->iters += 1;
+                if (lambda > 0.0) st->obj = st->obj + (at_lower ? lambda * st->s_rq : -(lambda * st->s_rq));
+                trace_put(a.trace, st->iters, st->obj);
                 if (tiny_pivot) st->tiny = 1;
             }
         } else if (tid == 0) {  // primal…:223-231
@@ -1487,6 +1504,8 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             st->flips += 1;
             st->open = 0;
             if (a.count_iter) st->iters += 1;
+            if (lambda > 0.0) st->obj = st->obj + (at_lower ? lambda * st->s_rq : -(lambda * st->s_rq));
+            trace_put(a.trace, st->iters, st->obj);
         }
     } else {
         // dual…:296-316
@@ -1542,6 +1561,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             st->cur = cur ^ 1;
             st->pivots += 1;
             st->iters += 1;
+            trace_put(a.trace, st->iters, st->obj);
             if (d_r != d_r || theta_p != theta_p) st->status = ELLP_ERR_NAN;
         }
         __syncthreads();
@@ -2207,6 +2227,9 @@ struct ellp_engine {
     uint64_t resyncs = 0;
     double *c_B = nullptr, *c_N = nullptr, *u = nullptr, *X = nullptr;
     double *x = nullptr, *lb = nullptr, *ub = nullptr, *d = nullptr;
+    double *trace_obj = nullptr;
+    unsigned long long *trace_it = nullptr;
+    int trace_len = 0;
     int32_t *binfo = nullptr;
     // blocked rebuild (ellp_rebuild.inc)
     double *bl_Cpart = nullptr, *bl_C = nullptr, *bl_V = nullptr, *bl_Vs = nullptr, *bl_Wp = nullptr, *bl_nzval = nullptr;
@@ -2462,6 +2485,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.ill_tol = e->ill_tol;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.count_iter = (MODE == 0 && e->lagged) ? 0 : 1;
+    a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
@@ -2735,6 +2759,7 @@ void launch_price2(ellp_engine *e, int use_pend) {
     a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.m = e->m; a.rpb = e->upd2_rows; a.use_pend = use_pend; a.ill_tol = e->ill_tol;
+    a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     int mine = e->nblocks - a.p.block0;
     if (mine > e->nbs) mine = e->nbs;
     if (mine < 0) mine = 0;
@@ -3145,6 +3170,12 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     ECHK(dmalloc(e, &e->aq_save, (size_t)ld));
     ECHK(dmalloc(e, &e->bmin, (size_t)(2 * m)));  // smallest | second smallest per row block
     ECHK(dmalloc(e, &e->binfo, (size_t)m));
+    e->trace_len = e->opts.trace_len > 0 ? e->opts.trace_len : 0;
+    if (e->trace_len > 0) {
+        ECHK(dmalloc(e, &e->trace_obj, (size_t)e->trace_len));
+        ECHK(dmalloc(e, &e->trace_it, (size_t)e->trace_len));
+        ECHK(hipMemsetAsync(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len, e->stream));
+    }
     if (m <= 8192) {  // blocked rebuild (k_bl_factor keeps m / 1024 rows per thread)
         const int64_t nrb64 = (m + 63) / 64;
         int sp = (int)((256 + nrb64 - 1) / nrb64);
@@ -3248,6 +3279,10 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
             UCHK(hipMemcpyAsync(e->y, y, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, e->stream));
             UCHK(hipMemcpyAsync(e->dd, d, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
             init.obj = host_dual_obj(m, n_c, b, bound_kind, lb, ub, y, d);  // dual…:184
+        } else {
+            double o = 0.0;  // standard_form.rs:48 `c.dot(x)`
+            for (int64_t i = 0; i < n_c; ++i) o += c[i] * x[i];
+            init.obj = o;
         }
         *e->h_st = init;
         UCHK(hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
@@ -3364,6 +3399,7 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
         a.max_iters = remaining < 16384 ? remaining : 16384;
         a.nch = (int)((e->nN + 63) / 64);
         a.eps = e->eps;
+        a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
         if (e->kind == ELLP_ENGINE_PRIMAL)
             hipLaunchKernelGGL(k_small<0>, dim3(1), dim3(SMALL_THREADS), e->small_lds, e->stream, a);
         else
@@ -3633,6 +3669,33 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
     return count;
 }
 
+int64_t ellp_engine_read_trace(ellp_engine *e, uint64_t *iters_out, double *obj_out, int64_t cap) {
+    if (!e || !iters_out || !obj_out || cap < 0) return ELLP_ERR_ARG;
+    if (e->trace_len <= 0) return 0;
+    if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
+    launch_flush(e);
+    std::vector<unsigned long long> it((size_t)e->trace_len);
+    std::vector<double> ob((size_t)e->trace_len);
+    if (hipMemcpyAsync(it.data(), e->trace_it, sizeof(unsigned long long) * it.size(), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipMemcpyAsync(ob.data(), e->trace_obj, sizeof(double) * ob.size(), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+        return ELLP_ERR_DEVICE;
+    // entries in iteration order: the ring position of iteration k is k % len; 0 marks an empty slot
+    unsigned long long newest = 0;
+    for (auto v : it) newest = v > newest ? v : newest;
+    int64_t n = 0;
+    const unsigned long long len = (unsigned long long)e->trace_len;
+    const unsigned long long first = newest >= len ? newest - len + 1 : 1;
+    for (unsigned long long k = first; k <= newest && n < cap; ++k) {
+        const size_t slot = (size_t)(k % len);
+        if (it[slot] != k) continue;  // an iteration that completed nothing (dropped for maintenance)
+        iters_out[n] = k;
+        obj_out[n] = ob[slot];
+        ++n;
+    }
+    return n;
+}
+
 ellp_status ellp_engine_request_maintenance(ellp_engine *e) {
     if (!e) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
@@ -3837,6 +3900,9 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     const int64_t cnt = e->m > e->nN ? e->m : e->nN;
     hipLaunchKernelGGL(k_rephase, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, c_dev, e->kindv,
                        e->B_index, e->N_index, e->c_B, e->c_N, e->Nb, e->m, e->nN);
+    hipLaunchKernelGGL(k_primal_obj, dim3(1), dim3(1024), 0, e->stream, e->c_B, e->c_N, e->x, e->B_index, e->N_index, e->m,
+                       e->nN, e->st);  // c.x with the new costs (the objective trace continues from it)
+    if (e->trace_len > 0) (void)hipMemsetAsync(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len, e->stream);
     // a new solve_with_initial starts here: status, counters and flags afresh; B^-1 and `cur` stay
     if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return bail(rc);
     if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return bail(rc);

@@ -72,7 +72,10 @@ typedef struct ellp_opts {
     int32_t pipeline;        /* launches per primal iteration: 0 = engine default, 1 = three (pricing | FTRAN |
                                 eta update), 2 = two (pricing | eta update of the previous pivot fused with this
                                 iteration's FTRAN: one pass over B^-1 instead of two) */
-    int32_t reserved[3];
+    int32_t trace_len;       /* > 0: keep the objective after each of the last `trace_len` iterations in a ring buffer on
+                                the device (ellp_engine_read_trace) — what the reference's `debug!("{iter} | {obj}")` line
+                                (primal…:161, dual…:189) prints; off by default, as the reference's logging is */
+    int32_t reserved[2];
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */
@@ -259,6 +262,14 @@ ellp_status ellp_engine_shard_info(ellp_engine *e, double *out6);
 int ellp_shard_select_compact(const double *packs, int world, int64_t ld, double eps, int64_t *q, int *src_rank,
                               int *src_slot);
 int64_t ellp_shard_pack_doubles(int64_t ld);
+
+/*
+ * The optional per-iteration objective trace (ellp_opts.trace_len > 0): the last entries of
+ * the ring, oldest first: iters_out[k] = the loop body just completed, obj_out[k] = the objective after it
+ * (primal: c.x carried by obj += +-lambda r_q per pivot from c.x at engine creation / hand-off; dual: the dual
+ * objective as the loop itself carries it, dual…:316).  Returns the number of entries written (<= cap).
+ */
+int64_t ellp_engine_read_trace(ellp_engine *e, uint64_t *iters_out, double *obj_out, int64_t cap);
 
 /* Debug/parity taps: copy an internal device vector to host. what: see ELLP_TAP_*. Returns
  * the number of doubles written (<= cap) or a negative ellp_status. */
