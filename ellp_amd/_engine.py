@@ -116,6 +116,8 @@ def lib():
     L.ellp_engine_poll.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t]
     L.ellp_engine_rephase.restype = C.c_int
     L.ellp_engine_rephase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_dual_rephase.restype = C.c_int
+    L.ellp_engine_dual_rephase.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_char_p, C.c_size_t]
     L.ellp_hip_qr_transposed.restype = C.c_int
     L.ellp_hip_qr_transposed.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     L.ellp_comm_unique_id.restype = C.c_int
@@ -369,6 +371,18 @@ class Engine:
         assert fp.c.size == fp.n_c == fp.kind.size == fp.lb.size == fp.ub.size
         err = C.create_string_buffer(512)
         s = lib().ellp_engine_rephase(self._h, _p(fp.c), _p(fp.kind), _p(fp.lb), _p(fp.ub), err, 512)
+        if s != OPTIMAL:
+            raise EllpHipError(s, err.value.decode())
+
+    def dual_rephase(self, c, b, kind, lb, ub):
+        """Dual phase-1 -> phase-2 hand-off on the device (same matrix in both phases).  The FlatProblem's
+        c/b/kind/lb/ub are replaced; read_point() afterwards brings x, N (in variable order), y, d back."""
+        fp = self.fp
+        fp.c, fp.b = _f64(c), _f64(b)
+        fp.kind = np.ascontiguousarray(kind, dtype=np.uint8)
+        fp.lb, fp.ub = _f64(lb), _f64(ub)
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_dual_rephase(self._h, _p(fp.c), _p(fp.b), _p(fp.kind), _p(fp.lb), _p(fp.ub), err, 512)
         if s != OPTIMAL:
             raise EllpHipError(s, err.value.decode())
 

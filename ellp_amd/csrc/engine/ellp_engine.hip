@@ -44,6 +44,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is bound with dlopen (see RcclApi)
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1729,6 +1730,7 @@ struct ResyncArgs {
     DevState *st;
     int64_t m, ld, nN;
     int cols_per_tile, ntiles;
+    int force;  // 1: adopt the recomputed x_B whatever the difference (phase hand-off of the dual)
 };
 __global__ __launch_bounds__(256) void k_resync_gather(ResyncArgs a) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1792,7 +1794,7 @@ __global__ __launch_bounds__(256) void k_resync_apply(ResyncArgs a) {
     if (a.st->need_rebuild) return;  // B^-1 failed its refresh: it is rebuilt first, then x_B is checked again
     const double maxdiff = __longlong_as_double((long long)a.maxbits[0]);
     const double maxx = __longlong_as_double((long long)a.maxbits[1]);
-    if (!(maxdiff > 1e-11 * (1.0 + maxx)) || isinf(maxdiff)) return;
+    if (!a.force && (!(maxdiff > 1e-11 * (1.0 + maxx)) || isinf(maxdiff))) return;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < a.m) a.x[a.B_index[i]] = a.cand[i];
 }
@@ -2177,6 +2179,65 @@ __global__ __launch_bounds__(1024) void k_primal_obj(const double *c_B, const do
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += s_p[w];
         st->obj = t;
+    }
+}
+
+// ---- DualPhase2::from(phase_1) on the device (dual_problem.rs:258-404), see ellp_engine_dual_rephase
+// nonbasic columns into variable-index order: dst[:, p] = src[:, perm[p]]
+__global__ __launch_bounds__(256) void k_permute_cols(const double *src, double *dst, const int64_t *perm, int64_t ld) {
+    const double2 *s = reinterpret_cast<const double2 *>(src + perm[blockIdx.x] * ld);
+    double2 *d = reinterpret_cast<double2 *>(dst + (int64_t)blockIdx.x * ld);
+    for (int64_t t = threadIdx.x; t < (ld >> 1); t += 256) d[t] = s[t];
+}
+struct DualRephaseArgs {
+    const double *A_N, *A_B, *y, *c;
+    const uint8_t *kind;
+    const double *lb, *ub;
+    const int64_t *N_index, *B_index;
+    double *dd, *x;
+    uint8_t *Nb;
+    DevState *st;
+    int64_t m, ld, nN;
+    double eps;
+};
+// one wave per variable: d_i = c_i - a_i . y (dual_problem.rs:284); nonbasic i: value and label by bound kind
+// and the sign of d_i, with the reference's assertions (:293-321)
+__global__ __launch_bounds__(256) void k_dual_rephase(DualRephaseArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= a.nN + a.m) return;
+    const bool nonbasic = w < a.nN;
+    const int64_t var = nonbasic ? a.N_index[w] : a.B_index[w - a.nN];
+    const double2 *col = reinterpret_cast<const double2 *>(nonbasic ? a.A_N + w * a.ld : a.A_B + (w - a.nN) * a.ld);
+    const double2 *y2 = reinterpret_cast<const double2 *>(a.y);
+    double acc = 0.0;
+    for (int64_t t = lane; t < (a.ld >> 1); t += WAVE) {
+        const double2 cv = col[t], yv = y2[t];
+        acc = fma(cv.x, yv.x, acc);
+        acc = fma(cv.y, yv.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane != 0) return;
+    const double di = a.c[var] - acc;
+    a.dd[var] = di;
+    if (!nonbasic) return;
+    double xi = 0.0;
+    int label = ELLP_NB_LOWER, bad = 0;
+    switch (a.kind[var]) {
+    case ELLP_BOUND_FREE: bad = !(fabs(di) < a.eps); xi = 0.0; label = ELLP_NB_FREE; break;
+    case ELLP_BOUND_LOWER: bad = !(di > -a.eps); xi = a.lb[var]; label = ELLP_NB_LOWER; break;
+    case ELLP_BOUND_UPPER: bad = !(di < a.eps); xi = a.ub[var]; label = ELLP_NB_UPPER; break;
+    case ELLP_BOUND_TWOSIDED:
+        if (di >= 0.0) { xi = a.lb[var]; label = ELLP_NB_LOWER; }
+        else { xi = a.ub[var]; label = ELLP_NB_UPPER; }
+        break;
+    default: xi = a.lb[var]; label = ELLP_NB_LOWER; break;  // Fixed
+    }
+    a.x[var] = xi;
+    a.Nb[w] = (uint8_t)label;
+    if (bad) {
+        a.st->panic_code = 293;  // the assert!s of dual_problem.rs:293-305
+        a.st->status = ELLP_ERR_PANIC;
     }
 }
 
@@ -2637,13 +2698,14 @@ int64_t default_period(const ellp_engine *e) {
 
 // periodic maintenance of B^-1: Newton-Schulz refresh, full rebuild only if that is not safe
 void launch_dleave(ellp_engine *e);
+void launch_resync(ellp_engine *e, int force);
 
 // x_B from the freshly maintained B^-1 (see k_resync_part)
-void launch_resync(ellp_engine *e) {
+void launch_resync(ellp_engine *e, int force) {
     if (e->nN <= 0) return;
     if (e->colshard) return;  // b - A_N x_N would need every rank's columns (a reduction over the ranks): not done
     ResyncArgs a{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
-                 e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles};
+                 e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles, force};
     (void)hipMemsetAsync(e->maxbits, 0, 2 * sizeof(unsigned long long), e->stream);
     a.cols_per_tile = (int)((e->nN + e->btran_tiles - 1) / e->btran_tiles);
     const int64_t half = e->ld >> 1;
@@ -2679,7 +2741,7 @@ void maintain_inverse(ellp_engine *e, bool reactive = false, bool rebuild = fals
     else launch_refresh(e);
     const char *mode = getenv("ELLP_RESYNC");  // diagnostics: "0" never, "1" only on reactive maintenance
     const bool want = mode && mode[0] == '0' ? false : (mode && mode[0] == '1' ? reactive : true);
-    if (want) launch_resync(e);
+    if (want) launch_resync(e, 0);
 }
 
 // After a read-back with the stream drained: iterations that were enqueued behind a stop (a final
@@ -2904,6 +2966,7 @@ ellp_status status_message(const DevState &s, char *errbuf, size_t errlen) {
     case ELLP_ERR_PANIC:
         if (s.panic_code == 402) set_err(errbuf, errlen, "assertion failed: lambda >= 0.");
         else if (s.panic_code == 229) set_err(errbuf, errlen, "pivot should have been unbounded");
+        else if (s.panic_code == 293) set_err(errbuf, errlen, "assertion failed: reduced cost of a nonbasic variable has the wrong sign (dual phase 2 construction)");
         else if (s.panic_code == 187) set_err(errbuf, errlen, "unwrap() on None in BTRAN");
         else if (s.panic_code == 295) set_err(errbuf, errlen, "unwrap() on None in FTRAN");
         else if (s.panic_code == 249) set_err(errbuf, errlen, "unwrap() on None in dual BTRAN");
@@ -3927,6 +3990,128 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     e->maint_chain = 0;
     e->enqueued = 0;
     e->iters_seen = 0;
+    return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const double *b, const uint8_t *bound_kind,
+                                     const double *lb, const double *ub, char *errbuf, size_t errlen) {
+    if (!e || !c || !b || !bound_kind || !lb || !ub) return ELLP_ERR_ARG;
+    if (errbuf && errlen) errbuf[0] = 0;
+    if (e->kind != ELLP_ENGINE_DUAL || e->small || e->colshard || e->world != 1) {
+        set_err(errbuf, errlen, "dual_rephase: a resident, unsharded dual engine of the explicit-inverse kind is needed");
+        return ELLP_ERR_ARG;
+    }
+    for (int64_t i = 0; i < e->n_c; ++i)
+        if (bound_kind[i] > 4) {
+            set_err(errbuf, errlen, "bound_kind[%lld] out of range", (long long)i);
+            return ELLP_ERR_ARG;
+        }
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int64_t m = e->m, nN = e->nN, ld = e->ld, n_c = e->n_c;
+    // ---- N in variable-index order (dual_problem.rs:286-323 enumerates `is_basic`), columns moved along
+    std::vector<int64_t> N((size_t)nN), perm((size_t)nN), Nsorted((size_t)nN);
+    if (nN > 0) HIPCHK(hipMemcpy(N.data(), e->N_index, sizeof(int64_t) * (size_t)nN, hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < nN; ++j) perm[(size_t)j] = j;
+    std::sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b2) { return N[(size_t)a] < N[(size_t)b2]; });
+    bool moved = false;
+    for (int64_t j = 0; j < nN; ++j) {
+        Nsorted[(size_t)j] = N[(size_t)perm[(size_t)j]];
+        moved = moved || perm[(size_t)j] != j;
+    }
+    double *c_dev = nullptr, *A2 = nullptr;
+    int64_t *perm_dev = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(e->stream);
+        if (c_dev) (void)hipFree(c_dev);
+        if (perm_dev) (void)hipFree(perm_dev);
+    };
+#define DCHK(expr)                                                                                        \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            cleanup();                                                                                    \
+            set_err(errbuf, errlen, "HIP error %s in ellp_engine_dual_rephase (%s)", hipGetErrorString(_e), #expr); \
+            return ELLP_ERR_DEVICE;                                                                       \
+        }                                                                                                 \
+    } while (0)
+    if (moved && nN > 0) {
+        DCHK(hipMalloc(reinterpret_cast<void **>(&A2), sizeof(double) * (size_t)(ld * nN)));
+        DCHK(hipMalloc(reinterpret_cast<void **>(&perm_dev), sizeof(int64_t) * (size_t)nN));
+        DCHK(hipMemcpyAsync(perm_dev, perm.data(), sizeof(int64_t) * (size_t)nN, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)nN), dim3(256), 0, e->stream, e->A_N, A2, perm_dev, ld);
+        DCHK(hipMemcpyAsync(e->N_index, Nsorted.data(), sizeof(int64_t) * (size_t)nN, hipMemcpyHostToDevice, e->stream));
+        DCHK(hipStreamSynchronize(e->stream));
+        for (auto &p : e->allocs)
+            if (p == e->A_N) {
+                (void)hipFree(p);
+                p = A2;
+            }
+        e->A_N = A2;
+    }
+    // ---- new costs, right-hand side, bounds
+    DCHK(hipMalloc(reinterpret_cast<void **>(&c_dev), sizeof(double) * (size_t)n_c));
+    DCHK(hipMemcpyAsync(c_dev, c, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+    DCHK(hipMemcpyAsync(e->b_dev, b, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, e->stream));
+    DCHK(hipMemcpyAsync(e->lb, lb, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+    DCHK(hipMemcpyAsync(e->ub, ub, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+    DCHK(hipMemcpyAsync(e->kindv, bound_kind, (size_t)n_c, hipMemcpyHostToDevice, e->stream));
+    const int64_t cnt = m > nN ? m : nN;
+    hipLaunchKernelGGL(k_rephase, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, e->stream, c_dev, e->kindv, e->B_index,
+                       e->N_index, e->c_B, e->c_N, e->Nb, m, nN);
+    // a new solve_with_initial: status and counters afresh (the maintenance kernels need a RUNNING engine)
+    DCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    DCHK(hipStreamSynchronize(e->stream));
+    DevState ns = *e->h_st;
+    ns.status = ST_RUNNING;
+    ns.nan_flag = 0;
+    ns.tiny = 0;
+    ns.need_rebuild = 0;
+    ns.panic_code = 0;
+    ns.iters = ns.pivots = ns.flips = 0;
+    ns.lr = -1;
+    *e->h_st = ns;
+    DCHK(hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+    // ---- y = B^-T c_B (:278-282), d = c - A^T y (:284), labels and values of the nonbasics (:286-323)
+    launch_btran(e);  // into e->u (a dual engine has no other use for it)
+    DCHK(hipMemcpyAsync(e->y, e->u, sizeof(double) * (size_t)ld, hipMemcpyDeviceToDevice, e->stream));
+    DCHK(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)n_c, e->stream));
+    DualRephaseArgs da{e->A_N, e->A_B, e->y, c_dev, e->kindv, e->lb, e->ub, e->N_index, e->B_index, e->dd, e->x, e->Nb,
+                       e->st, m, ld, nN, e->eps};
+    hipLaunchKernelGGL(k_dual_rephase, dim3((unsigned)((nN + m + 3) / 4)), dim3(256), 0, e->stream, da);
+    // ---- x_B = B^-1 (b - A_N x_N) (:327-328)
+    launch_resync(e, 1);
+    // ---- the loop's own entry assertion (dual…:139-151) and the dual objective (:184)
+    std::vector<double> y((size_t)m), d((size_t)n_c), lbv(lb, lb + n_c), ubv(ub, ub + n_c);
+    std::vector<uint8_t> Nb((size_t)(nN > 0 ? nN : 1));
+    DCHK(hipMemcpyAsync(y.data(), e->y, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, e->stream));
+    DCHK(hipMemcpyAsync(d.data(), e->dd, sizeof(double) * (size_t)n_c, hipMemcpyDeviceToHost, e->stream));
+    if (nN > 0) DCHK(hipMemcpyAsync(Nb.data(), e->Nb, (size_t)nN, hipMemcpyDeviceToHost, e->stream));
+    DCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    DCHK(hipStreamSynchronize(e->stream));
+    DCHK(hipGetLastError());
+    cleanup();
+#undef DCHK
+    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    for (int64_t j = 0; j < nN; ++j) {
+        const double di = d[(size_t)Nsorted[(size_t)j]];
+        bool infeasible;
+        if (Nb[(size_t)j] == ELLP_NB_LOWER) infeasible = di < -e->eps;
+        else if (Nb[(size_t)j] == ELLP_NB_UPPER) infeasible = di > e->eps;
+        else infeasible = std::fabs(di) > e->eps;
+        if (infeasible) {
+            set_err(errbuf, errlen, "initial point of dual phase 2 is dual infeasible");
+            return ELLP_ERR_PANIC;
+        }
+    }
+    const double obj = host_dual_obj(m, n_c, b, bound_kind, lb, ub, y.data(), d.data());
+    HIPCHK(hipMemcpy(&e->st->obj, &obj, sizeof(double), hipMemcpyHostToDevice));
+    e->h_st->obj = obj;
+    e->need_dleave = true;
+    e->maint_chain = 0;
+    e->enqueued = 0;
+    e->iters_seen = 0;
+    if (e->trace_len > 0) HIPCHK(hipMemset(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len));
     return ELLP_OPTIMAL;
 }
 

@@ -144,6 +144,10 @@ struct DualPhase2 {  // :69-73
     DualFeasiblePoint point;
     double obj() const { return std_form.dual_obj(point.y, point.d); }
     static DualPhase2 from_phase1(DualPhase1 phase_1);  // :258-404
+    // the same without its linear algebra: original standard form, B mapped through the variable ids, N listed
+    // in variable order with placeholder labels, x / y / d zero — for the device hand-off
+    // (ellp_engine_dual_rephase), which fills them in
+    static DualPhase2 shell_from_phase1(DualPhase1 phase_1);
 };
 
 enum class SolutionStatus { Optimal, Infeasible, Unbounded, MaxIter };  // src/solver.rs:27-33

@@ -292,4 +292,25 @@ DualPhase2 DualPhase2::from_phase1(DualPhase1 phase_1) {
     return p2;
 }
 
+DualPhase2 DualPhase2::shell_from_phase1(DualPhase1 phase_1) {
+    const Problem &phase_1_prob = phase_1.std_form.prob;
+    StandardForm std_form = std::move(phase_1.orig_std_form);
+    std::vector<char> is_basic(std_form.cols(), 0);
+    std::vector<Basic> B;
+    for (const auto &b : phase_1.point.point.B) {  // dual_problem.rs:264-274
+        const size_t index = phase_1_prob.variables[b.index].id;
+        is_basic[index] = 1;
+        B.push_back({index});
+    }
+    std::vector<Nonbasic> N;
+    for (size_t i = 0; i < is_basic.size(); ++i)
+        if (!is_basic[i]) N.push_back({i, NonbasicBound::Lower});
+    DualPhase2 p2;
+    p2.point = DualFeasiblePoint{std::vector<double>(static_cast<size_t>(std_form.A.rows), 0.0),
+                                 std::vector<double>(std_form.bounds.size(), 0.0),
+                                 Point{std::vector<double>(std_form.bounds.size(), 0.0), std::move(N), std::move(B)}};
+    p2.std_form = std::move(std_form);
+    return p2;
+}
+
 }  // namespace ellp

@@ -213,14 +213,55 @@ SolutionStatus DualSimplexSolver::solve_with_initial(const StandardForm &sf, Dua
     return out;
 }
 
-// dual_simplex_solver.rs:33-108
+namespace {
+// one phase of the dual method on a resident engine: run, bring the point and the duals back
+SolutionStatus run_resident_dual(ellp_engine *e, std::uint64_t max_iter, Flat &f, DualFeasiblePoint &dp, std::uint64_t *iters) {
+    ellp_stats st{};
+    char err[512] = {0};
+    const ellp_status s = ellp_engine_run(e, max_iter, &st, err, sizeof(err));
+    if (iters) *iters = st.iters;
+    const SolutionStatus out = to_status(s, err);
+    const ellp_status rs = ellp_engine_read_point(e, dp.point.x.data(), f.B.data(), f.N.data(), f.Nb.data(), dp.y.data(),
+                                                  dp.d.data(), err, sizeof(err));
+    if (rs != ELLP_OPTIMAL) to_status(rs, err);
+    unflatten(f, dp.point);
+    return out;
+}
+}  // namespace
+
+// dual_simplex_solver.rs:33-108.  Where the engine is of the explicit-inverse kind (m > 128) and the box
+// problem of phase 1 has the original standard form's matrix (no TwoSided / Fixed variable was dropped,
+// dual_problem.rs:96-112), the two solve_with_initial calls are two slices of ONE resident engine:
+// DualPhase2::from(phase_1) (dual_problem.rs:258-404) is done on the device from the resident B^-1
+// (ellp_engine_dual_rephase) — the matrix is uploaded once and no LU is computed on the host.
 SolverResult DualSimplexSolver::solve(Problem prob) const {
     SolverResult res;
     Problem orig_for_fallback = prob;  // phase_1.into_orig_prob()
     auto p1 = DualPhase1::from_problem(std::move(prob));
     if (!p1) { res.kind = SolverResult::Infeasible; return res; }
     DualPhase1 phase_1 = std::move(*p1);
-    switch (solve_with_initial(phase_1.std_form, phase_1.point, &res.iters_phase1)) {
+    const StandardForm &sf1 = phase_1.std_form;
+    const bool resident = sf1.rows() > 128 && !phase_1.point.point.N.empty() &&
+                          sf1.rows() == phase_1.orig_std_form.rows() && sf1.cols() == phase_1.orig_std_form.cols() &&
+                          sf1.bounds.size() == phase_1.orig_std_form.bounds.size() && sf1.A.a == phase_1.orig_std_form.A.a;
+    EngineHandle eng;
+    SolutionStatus s1;
+    if (resident) {
+        Flat f1 = flatten(sf1, phase_1.point.point);
+        const ellp_opts o = make_opts(max_iter_, engine_);
+        char err[512] = {0};
+        const ellp_status cs = ellp_engine_create(
+            ELLP_ENGINE_DUAL, static_cast<std::int64_t>(sf1.rows()), static_cast<std::int64_t>(sf1.cols()),
+            static_cast<std::int64_t>(sf1.bounds.size()), sf1.A.a.data(), sf1.c.data(), sf1.b.data(), f1.kind.data(),
+            f1.lb.data(), f1.ub.data(), phase_1.point.point.x.data(), f1.B.data(), static_cast<std::int64_t>(f1.B.size()),
+            f1.N.data(), f1.Nb.data(), static_cast<std::int64_t>(f1.N.size()), phase_1.point.y.data(),
+            phase_1.point.d.data(), &o, &eng.e, err, sizeof(err));
+        if (cs != ELLP_OPTIMAL) to_status(cs, err);
+        s1 = run_resident_dual(eng.e, max_iter_, f1, phase_1.point, &res.iters_phase1);
+    } else {
+        s1 = solve_with_initial(phase_1.std_form, phase_1.point, &res.iters_phase1);
+    }
+    switch (s1) {
     case SolutionStatus::Optimal: {
         const double obj = phase_1.obj();
         if (!(obj < EPS)) throw EllPPanic("assertion failed: obj < EPS");
@@ -240,8 +281,21 @@ SolverResult DualSimplexSolver::solve(Problem prob) const {
         res.max_iter_obj = std::numeric_limits<double>::infinity();
         return res;
     }
-    DualPhase2 phase_2 = DualPhase2::from_phase1(std::move(phase_1));
-    switch (solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2)) {
+    DualPhase2 phase_2;
+    SolutionStatus s2;
+    if (resident) {
+        phase_2 = DualPhase2::shell_from_phase1(std::move(phase_1));
+        Flat f2 = flatten(phase_2.std_form, phase_2.point.point);
+        char err[512] = {0};
+        const ellp_status rs = ellp_engine_dual_rephase(eng.e, phase_2.std_form.c.data(), phase_2.std_form.b.data(),
+                                                        f2.kind.data(), f2.lb.data(), f2.ub.data(), err, sizeof(err));
+        if (rs != ELLP_OPTIMAL) to_status(rs, err);  // the reference's assertions on the sign of d come back as panics
+        s2 = run_resident_dual(eng.e, max_iter_, f2, phase_2.point, &res.iters_phase2);
+    } else {
+        phase_2 = DualPhase2::from_phase1(std::move(phase_1));
+        s2 = solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2);
+    }
+    switch (s2) {
     case SolutionStatus::Optimal:
         res.kind = SolverResult::Optimal;
         res.solution = Solution{std::move(phase_2.std_form), std::move(phase_2.point.point)};

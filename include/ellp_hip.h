@@ -207,6 +207,20 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
                                 const double *ub, char *errbuf, size_t errbuf_len);
 
 /*
+ * The dual method's phase-1 -> phase-2 hand-off without leaving HBM (SURVEY.md §8 f2;
+ * DualPhase2::from(phase_1), dual_problem.rs:258-404) for the common case that the box problem of phase 1
+ * has the same matrix as the original standard form (no TwoSided / Fixed variable was dropped,
+ * dual_problem.rs:96-112 — the caller checks that).  With the basis phase 1 ended on and the resident
+ * B^-1: y = B^-T c_B, d = c - A^T y, every nonbasic variable to the bound its kind and the sign of d_i
+ * name (with the reference's assertions), N re-listed in variable order (columns moved along on the
+ * device), x_B = B^-1 (b - A_N x_N), the dual objective, status and counters afresh.  c, kind, lb, ub:
+ * n_c entries of the ORIGINAL standard form; b: m entries.  Engines of the explicit-inverse kind only
+ * (m > 128): the persistent small-LP kernel carries no inverse — re-create the engine there.
+ */
+ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const double *b, const uint8_t *bound_kind,
+                                     const double *lb, const double *ub, char *errbuf, size_t errbuf_len);
+
+/*
  * The same sharded loop driven from inside the library, with the exchange done by RCCL directly
  * on the engine's stream (ncclAllGather, in place, seg doubles per rank) — no host language in the
  * per-iteration path.  RCCL is bound at run time (dlopen; `rccl_path` may name the library the
