@@ -116,6 +116,9 @@ def lib():
     L.ellp_engine_poll.argtypes = [C.c_void_p, C.POINTER(Stats), C.c_char_p, C.c_size_t]
     L.ellp_engine_rephase.restype = C.c_int
     L.ellp_engine_rephase.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.ellp_engine_create_primal_phase1.restype = C.c_int
+    L.ellp_engine_create_primal_phase1.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 7 + [
+        C.POINTER(Opts), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
     L.ellp_engine_dual_rephase.restype = C.c_int
     L.ellp_engine_dual_rephase.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_char_p, C.c_size_t]
     L.ellp_hip_qr_transposed.restype = C.c_int
@@ -263,6 +266,32 @@ class Engine:
         if s != OPTIMAL:
             self._h = C.c_void_p()
             raise EllpHipError(s, err.value.decode())
+
+    @classmethod
+    def primal_phase1(cls, m, n, A, b, kind, lb, ub, x, Nb, opts=None):
+        """Primal phase 1 built on the device (ellp_engine_create_primal_phase1): the standard form and the
+        nonbasic start of the n original variables in, an engine with n + m columns out.  Its FlatProblem holds
+        the phase-1 arrays as the engine defines them (A is not materialised on the host: fp.A is empty)."""
+        m, n = int(m), int(n)
+        nt = n + m
+        A_ = _f64(A).reshape(-1)
+        assert A_.size == m * n
+        kind_ = np.concatenate([np.ascontiguousarray(kind, dtype=np.uint8)[:n], np.full(m, 1, dtype=np.uint8)])
+        fp = FlatProblem(m, nt, nt, np.zeros(0), np.concatenate([np.zeros(n), np.ones(m)]), b, kind_,
+                         np.concatenate([_f64(lb)[:n], np.zeros(m)]), np.concatenate([_f64(ub)[:n], np.zeros(m)]),
+                         np.concatenate([_f64(x)[:n], np.zeros(m)]), np.arange(n, nt, dtype=np.int64),
+                         np.arange(n, dtype=np.int64), np.ascontiguousarray(Nb, dtype=np.uint8)[:n])
+        self = cls.__new__(cls)
+        self.fp, self.kind, self._h = fp, ENGINE_PRIMAL, C.c_void_p()
+        o = opts or default_opts()
+        err = C.create_string_buffer(512)
+        xs, Nbs = _f64(x)[:n].copy(), np.ascontiguousarray(Nb, dtype=np.uint8)[:n].copy()
+        s = lib().ellp_engine_create_primal_phase1(m, n, _p(A_), _p(fp.b), _p(kind_), _p(fp.lb), _p(fp.ub), _p(xs), _p(Nbs),
+                                                   C.byref(o), C.byref(self._h), err, 512)
+        if s != OPTIMAL:
+            self._h = C.c_void_p()
+            raise EllpHipError(s, err.value.decode())
+        return self
 
     def run(self, max_iters):
         st = Stats()

@@ -2241,6 +2241,18 @@ __global__ __launch_bounds__(256) void k_dual_rephase(DualRephaseArgs a) {
     }
 }
 
+// primal_problem.rs:236-246: the artificial column of row i is signum(b~_i) e_i (f64::signum: +1 for +0.0,
+// -1 for -0.0) and its variable starts at |b~_i|; b~ = b - A v is in `bt`.  Basic position i holds artificial i.
+__global__ __launch_bounds__(256) void k_phase1_art(const double *bt, double *A_B, double *x, const int64_t *B_index,
+                                                    int64_t m, int64_t ld) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double v = bt[i];
+    const double sgn = (v != v) ? v : (signbit(v) ? -1.0 : 1.0);
+    A_B[i * ld + i] = sgn;
+    x[B_index[i]] = fabs(v);
+}
+
 // phase hand-off (ellp_engine_rephase): re-gather the costs by the current index sets and relabel the
 // nonbasic variables that became Free
 __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t *kind, const int64_t *B_index,
@@ -3073,11 +3085,14 @@ void ellp_engine_destroy(ellp_engine *e) {
     delete e;
 }
 
-ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+// n_explicit: columns of A the caller passes; columns n_explicit .. n-1 (m of them, or none) are the
+// artificial columns of primal phase 1 and are made on the device (build_phase1)
+static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
                                const double *b, const uint8_t *bound_kind, const double *lb, const double *ub,
                                const double *x, const int64_t *B_index, int64_t n_B, const int64_t *N_index,
                                const uint8_t *N_bound, int64_t n_N, const double *y, const double *d,
-                               const ellp_opts *opts_in, ellp_engine **out, char *errbuf, size_t errlen) {
+                               const ellp_opts *opts_in, ellp_engine **out, char *errbuf, size_t errlen,
+                               int64_t n_explicit, bool build_phase1) {
     if (!out) return ELLP_ERR_ARG;
     *out = nullptr;
     if (errbuf && errlen) errbuf[0] = 0;
@@ -3310,7 +3325,9 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         hipError_t _u = (expr);                 \
         if (_u != hipSuccess) { ECHK(fail(_u)); } \
     } while (0)
-        UCHK(hipMemcpyAsync(A_full, A, sizeof(double) * (size_t)(m * n), hipMemcpyHostToDevice, e->stream));
+        UCHK(hipMemcpyAsync(A_full, A, sizeof(double) * (size_t)(m * n_explicit), hipMemcpyHostToDevice, e->stream));
+        if (n_explicit < n)  // the artificial columns: zero here, their +-1 is set once b~ is known (k_phase1_art)
+            UCHK(hipMemsetAsync(A_full + m * n_explicit, 0, sizeof(double) * (size_t)(m * (n - n_explicit)), e->stream));
         UCHK(hipMemcpyAsync(c_full, c, sizeof(double) * (size_t)n_c, hipMemcpyHostToDevice, e->stream));
         UCHK(hipMemcpyAsync(e->B_index, B_index, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, e->stream));
         if (n_N > 0) {
@@ -3353,6 +3370,19 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
         (void)hipFree(A_full);
         (void)hipFree(c_full);
 #undef UCHK
+    }
+    if (build_phase1) {
+        // primal_problem.rs:236-246 on the device: b~ = b - A v over the nonbasic (= all structural) columns,
+        // artificial column i = signum(b~_i) e_i with value |b~_i| (the kernels of launch_resync form b - A_N x_N)
+        ResyncArgs ra{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
+                      e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles, 0};
+        ra.cols_per_tile = (int)((e->nN + e->btran_tiles - 1) / e->btran_tiles);
+        const int64_t half = e->ld >> 1;
+        hipLaunchKernelGGL(k_resync_gather, dim3((unsigned)((e->nN + 255) / 256)), dim3(256), 0, e->stream, ra);
+        hipLaunchKernelGGL(k_resync_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0, e->stream, ra);
+        hipLaunchKernelGGL(k_resync_rhs, dim3((unsigned)((e->ld + 255) / 256)), dim3(256), 0, e->stream, ra);
+        hipLaunchKernelGGL(k_phase1_art, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->tvec, e->A_B, e->x,
+                           e->B_index, m, e->ld);
     }
     // dual: initial dual feasibility assertion (dual…:139-151) — host side, data is in hand
     if (kind == ELLP_ENGINE_DUAL) {
@@ -3421,6 +3451,48 @@ ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, cons
     e->t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *out = e;
     return ELLP_OPTIMAL;
+}
+
+ellp_status ellp_engine_create(int kind, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                               const double *b, const uint8_t *bound_kind, const double *lb, const double *ub,
+                               const double *x, const int64_t *B_index, int64_t n_B, const int64_t *N_index,
+                               const uint8_t *N_bound, int64_t n_N, const double *y, const double *d,
+                               const ellp_opts *opts_in, ellp_engine **out, char *errbuf, size_t errlen) {
+    return engine_create_impl(kind, m, n, n_c, A, c, b, bound_kind, lb, ub, x, B_index, n_B, N_index, N_bound, n_N, y, d,
+                              opts_in, out, errbuf, errlen, n, false);
+}
+
+ellp_status ellp_engine_create_primal_phase1(int64_t m, int64_t n, const double *A, const double *b,
+                                             const uint8_t *bound_kind, const double *lb, const double *ub,
+                                             const double *x, const uint8_t *N_bound, const ellp_opts *opts_in,
+                                             ellp_engine **out, char *errbuf, size_t errlen) {
+    if (!out) return ELLP_ERR_ARG;
+    *out = nullptr;
+    if (m <= 0 || n <= 0 || !A || !b || !bound_kind || !lb || !ub || !x || !N_bound) {
+        set_err(errbuf, errlen, "null pointer or inconsistent sizes");
+        return ELLP_ERR_ARG;
+    }
+    // the phase-1 problem (primal_problem.rs:137-141, :236-253): costs 0 on the originals and 1 on the m
+    // artificials, the artificials Lower(0) and basic, every original variable nonbasic at the bound the
+    // caller names
+    const int64_t nt = n + m;
+    std::vector<double> c((size_t)nt, 0.0), lb2((size_t)nt, 0.0), ub2((size_t)nt, 0.0), x2((size_t)nt, 0.0);
+    std::vector<uint8_t> kind2((size_t)nt, (uint8_t)ELLP_BOUND_LOWER), Nb(N_bound, N_bound + n);
+    std::vector<int64_t> B((size_t)m), N((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+        kind2[(size_t)j] = bound_kind[j];
+        lb2[(size_t)j] = lb[j];
+        ub2[(size_t)j] = ub[j];
+        x2[(size_t)j] = x[j];
+        N[(size_t)j] = j;
+    }
+    for (int64_t i = 0; i < m; ++i) {
+        c[(size_t)(n + i)] = 1.0;
+        B[(size_t)i] = n + i;
+    }
+    return engine_create_impl(ELLP_ENGINE_PRIMAL, m, nt, nt, A, c.data(), b, kind2.data(), lb2.data(), ub2.data(),
+                              x2.data(), B.data(), m, N.data(), Nb.data(), n, nullptr, nullptr, opts_in, out, errbuf, errlen,
+                              n, true);
 }
 
 // The explicit-inverse engine is about to be used on an engine that has been running k_small: build

@@ -162,6 +162,22 @@ ellp_status ellp_engine_create(
     const double *y, const double *d, /* dual only, else NULL */
     const ellp_opts *opts, ellp_engine **out, char *errbuf, size_t errbuf_len);
 
+/*
+ * Primal phase 1 built ON THE DEVICE (primal_problem.rs:236-246, the branch without free
+ * variables): the caller passes the standard form (A m x n, b, bounds) and the nonbasic start it has chosen
+ * for the n original variables (x[j] = the bound value, N_bound[j] = its label, primal_problem.rs:95-135);
+ * the engine appends the m artificial columns itself — b~ = b - A x (one pass over A in HBM), column n+i =
+ * signum(b~_i) e_i, value |b~_i|, cost 1, Lower(0), basic — so neither the m x m block nor b~ is computed or
+ * uploaded by the host.  The resulting engine has n + m columns (read_point sizes) and is what
+ * ellp_engine_create would have built from the phase-1 arrays of the reference.
+ */
+ellp_status ellp_engine_create_primal_phase1(
+    int64_t m, int64_t n,
+    const double *A, const double *b,
+    const uint8_t *bound_kind, const double *lb, const double *ub,
+    const double *x, const uint8_t *N_bound,
+    const ellp_opts *opts, ellp_engine **out, char *errbuf, size_t errbuf_len);
+
 ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats,
                             char *errbuf, size_t errbuf_len);
 
