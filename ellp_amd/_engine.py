@@ -119,6 +119,9 @@ def lib():
     L.ellp_engine_create_primal_phase1.restype = C.c_int
     L.ellp_engine_create_primal_phase1.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 7 + [
         C.POINTER(Opts), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.ellp_engine_create_dual_phase1.restype = C.c_int
+    L.ellp_engine_create_dual_phase1.argtypes = [C.c_int64, C.c_int64] + [C.c_void_p] * 8 + [
+        C.POINTER(Opts), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
     L.ellp_engine_dual_rephase.restype = C.c_int
     L.ellp_engine_dual_rephase.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_char_p, C.c_size_t]
     L.ellp_hip_qr_transposed.restype = C.c_int
@@ -288,6 +291,25 @@ class Engine:
         xs, Nbs = _f64(x)[:n].copy(), np.ascontiguousarray(Nb, dtype=np.uint8)[:n].copy()
         s = lib().ellp_engine_create_primal_phase1(m, n, _p(A_), _p(fp.b), _p(kind_), _p(fp.lb), _p(fp.ub), _p(xs), _p(Nbs),
                                                    C.byref(o), C.byref(self._h), err, 512)
+        if s != OPTIMAL:
+            self._h = C.c_void_p()
+            raise EllpHipError(s, err.value.decode())
+        return self
+
+    @classmethod
+    def dual_phase1(cls, m, n, A, c, b, kind, lb, ub, B, N, opts=None):
+        """DualPhase1::new's point made on the device (ellp_engine_create_dual_phase1): the box problem's standard
+        form and the basis the LU of A^T picked in, a dual engine with y, d, x and the nonbasic labels out
+        (read_point brings them into self.fp)."""
+        m, n = int(m), int(n)
+        fp = FlatProblem(m, n, n, A, c, b, kind, lb, ub, np.zeros(n), B, N, np.zeros(n - m, dtype=np.uint8),
+                         y=np.zeros(m), d=np.zeros(n))
+        self = cls.__new__(cls)
+        self.fp, self.kind, self._h = fp, ENGINE_DUAL, C.c_void_p()
+        o = opts or default_opts()
+        err = C.create_string_buffer(512)
+        s = lib().ellp_engine_create_dual_phase1(m, n, _p(fp.A), _p(fp.c), _p(fp.b), _p(fp.kind), _p(fp.lb), _p(fp.ub),
+                                                 _p(fp.B), _p(fp.N), C.byref(o), C.byref(self._h), err, 512)
         if s != OPTIMAL:
             self._h = C.c_void_p()
             raise EllpHipError(s, err.value.decode())

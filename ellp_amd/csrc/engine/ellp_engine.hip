@@ -2199,9 +2199,10 @@ struct DualRephaseArgs {
     DevState *st;
     int64_t m, ld, nN;
     double eps;
+    int phase1;  // DualPhase1::new's labelling (dual_problem.rs:177-203) instead of DualPhase2::from's (:286-323)
 };
-// one wave per variable: d_i = c_i - a_i . y (dual_problem.rs:284); nonbasic i: value and label by bound kind
-// and the sign of d_i, with the reference's assertions (:293-321)
+// one wave per variable: d_i = c_i - a_i . y (dual_problem.rs:284 / :173); nonbasic i: value and label by bound
+// kind and the sign of d_i, with the reference's assertions (:293-321 / :201)
 __global__ __launch_bounds__(256) void k_dual_rephase(DualRephaseArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -2223,6 +2224,19 @@ __global__ __launch_bounds__(256) void k_dual_rephase(DualRephaseArgs a) {
     if (!nonbasic) return;
     double xi = 0.0;
     int label = ELLP_NB_LOWER, bad = 0;
+    if (a.phase1) {
+        const int k = a.kind[var];
+        label = di >= 0.0 ? ELLP_NB_LOWER : ELLP_NB_UPPER;
+        if (k == ELLP_BOUND_TWOSIDED) xi = di >= 0.0 ? a.lb[var] : a.ub[var];
+        else if (k == ELLP_BOUND_FIXED) xi = a.lb[var];
+        else {
+            a.st->panic_code = 201;  // "bounds should always be fixed or two-sided" (dual_problem.rs:201)
+            a.st->status = ELLP_ERR_PANIC;
+        }
+        a.x[var] = xi;
+        a.Nb[w] = (uint8_t)label;
+        return;
+    }
     switch (a.kind[var]) {
     case ELLP_BOUND_FREE: bad = !(fabs(di) < a.eps); xi = 0.0; label = ELLP_NB_FREE; break;
     case ELLP_BOUND_LOWER: bad = !(di > -a.eps); xi = a.lb[var]; label = ELLP_NB_LOWER; break;
@@ -2979,6 +2993,7 @@ ellp_status status_message(const DevState &s, char *errbuf, size_t errlen) {
         if (s.panic_code == 402) set_err(errbuf, errlen, "assertion failed: lambda >= 0.");
         else if (s.panic_code == 229) set_err(errbuf, errlen, "pivot should have been unbounded");
         else if (s.panic_code == 293) set_err(errbuf, errlen, "assertion failed: reduced cost of a nonbasic variable has the wrong sign (dual phase 2 construction)");
+        else if (s.panic_code == 201) set_err(errbuf, errlen, "bounds should always be fixed or two-sided");
         else if (s.panic_code == 187) set_err(errbuf, errlen, "unwrap() on None in BTRAN");
         else if (s.panic_code == 295) set_err(errbuf, errlen, "unwrap() on None in FTRAN");
         else if (s.panic_code == 249) set_err(errbuf, errlen, "unwrap() on None in dual BTRAN");
@@ -4065,6 +4080,42 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     return ELLP_OPTIMAL;
 }
 
+// y = B^-T c_B, d = c - A^T y, labels and values of the nonbasic variables, x_B = B^-1 (b - A_N x_N), all from the
+// resident B^-1: the common part of DualPhase2::from (dual_problem.rs:278-328; labels :286-323) and of
+// DualPhase1::new (:165-214; labels :177-203, `phase1`).  Ends with the loop's own entry assertion
+// (dual_simplex_solver.rs:139-151).  c_dev: the costs by variable index, on the device.
+static ellp_status dual_point_from_inverse(ellp_engine *e, const double *c_dev, int phase1, const int64_t *N_host,
+                                           char *errbuf, size_t errlen) {
+    const int64_t m = e->m, nN = e->nN, ld = e->ld, n_c = e->n_c;
+    launch_btran(e);  // into e->u (a dual engine has no other use for it)
+    HIPCHK(hipMemcpyAsync(e->y, e->u, sizeof(double) * (size_t)ld, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)n_c, e->stream));
+    DualRephaseArgs da{e->A_N, e->A_B, e->y, c_dev, e->kindv, e->lb, e->ub, e->N_index, e->B_index, e->dd, e->x, e->Nb,
+                       e->st, m, ld, nN, e->eps, phase1};
+    hipLaunchKernelGGL(k_dual_rephase, dim3((unsigned)((nN + m + 3) / 4)), dim3(256), 0, e->stream, da);
+    launch_resync(e, 1);
+    std::vector<double> d((size_t)n_c);
+    std::vector<uint8_t> Nb((size_t)(nN > 0 ? nN : 1));
+    HIPCHK(hipMemcpyAsync(d.data(), e->dd, sizeof(double) * (size_t)n_c, hipMemcpyDeviceToHost, e->stream));
+    if (nN > 0) HIPCHK(hipMemcpyAsync(Nb.data(), e->Nb, (size_t)nN, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    for (int64_t j = 0; j < nN; ++j) {
+        const double di = d[(size_t)N_host[(size_t)j]];
+        bool infeasible;
+        if (Nb[(size_t)j] == ELLP_NB_LOWER) infeasible = di < -e->eps;
+        else if (Nb[(size_t)j] == ELLP_NB_UPPER) infeasible = di > e->eps;
+        else infeasible = std::fabs(di) > e->eps;
+        if (infeasible) {
+            set_err(errbuf, errlen, "initial point of dual phase 2 is dual infeasible");
+            return ELLP_ERR_PANIC;
+        }
+    }
+    return ELLP_OPTIMAL;
+}
+
 ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const double *b, const uint8_t *bound_kind,
                                      const double *lb, const double *ub, char *errbuf, size_t errlen) {
     if (!e || !c || !b || !bound_kind || !lb || !ub) return ELLP_ERR_ARG;
@@ -4144,38 +4195,13 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
     ns.lr = -1;
     *e->h_st = ns;
     DCHK(hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
-    // ---- y = B^-T c_B (:278-282), d = c - A^T y (:284), labels and values of the nonbasics (:286-323)
-    launch_btran(e);  // into e->u (a dual engine has no other use for it)
-    DCHK(hipMemcpyAsync(e->y, e->u, sizeof(double) * (size_t)ld, hipMemcpyDeviceToDevice, e->stream));
-    DCHK(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)n_c, e->stream));
-    DualRephaseArgs da{e->A_N, e->A_B, e->y, c_dev, e->kindv, e->lb, e->ub, e->N_index, e->B_index, e->dd, e->x, e->Nb,
-                       e->st, m, ld, nN, e->eps};
-    hipLaunchKernelGGL(k_dual_rephase, dim3((unsigned)((nN + m + 3) / 4)), dim3(256), 0, e->stream, da);
-    // ---- x_B = B^-1 (b - A_N x_N) (:327-328)
-    launch_resync(e, 1);
-    // ---- the loop's own entry assertion (dual…:139-151) and the dual objective (:184)
-    std::vector<double> y((size_t)m), d((size_t)n_c), lbv(lb, lb + n_c), ubv(ub, ub + n_c);
-    std::vector<uint8_t> Nb((size_t)(nN > 0 ? nN : 1));
-    DCHK(hipMemcpyAsync(y.data(), e->y, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, e->stream));
-    DCHK(hipMemcpyAsync(d.data(), e->dd, sizeof(double) * (size_t)n_c, hipMemcpyDeviceToHost, e->stream));
-    if (nN > 0) DCHK(hipMemcpyAsync(Nb.data(), e->Nb, (size_t)nN, hipMemcpyDeviceToHost, e->stream));
-    DCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
-    DCHK(hipStreamSynchronize(e->stream));
-    DCHK(hipGetLastError());
+    const ellp_status ps = dual_point_from_inverse(e, c_dev, 0, Nsorted.data(), errbuf, errlen);
     cleanup();
 #undef DCHK
-    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
-    for (int64_t j = 0; j < nN; ++j) {
-        const double di = d[(size_t)Nsorted[(size_t)j]];
-        bool infeasible;
-        if (Nb[(size_t)j] == ELLP_NB_LOWER) infeasible = di < -e->eps;
-        else if (Nb[(size_t)j] == ELLP_NB_UPPER) infeasible = di > e->eps;
-        else infeasible = std::fabs(di) > e->eps;
-        if (infeasible) {
-            set_err(errbuf, errlen, "initial point of dual phase 2 is dual infeasible");
-            return ELLP_ERR_PANIC;
-        }
-    }
+    if (ps != ELLP_OPTIMAL) return ps;
+    std::vector<double> y((size_t)m), d((size_t)n_c);
+    HIPCHK(hipMemcpy(y.data(), e->y, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(d.data(), e->dd, sizeof(double) * (size_t)n_c, hipMemcpyDeviceToHost));
     const double obj = host_dual_obj(m, n_c, b, bound_kind, lb, ub, y.data(), d.data());
     HIPCHK(hipMemcpy(&e->st->obj, &obj, sizeof(double), hipMemcpyHostToDevice));
     e->h_st->obj = obj;
@@ -4184,6 +4210,68 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
     e->enqueued = 0;
     e->iters_seen = 0;
     if (e->trace_len > 0) HIPCHK(hipMemset(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len));
+    return ELLP_OPTIMAL;
+}
+
+// DualPhase1::new's point (dual_problem.rs:162-214) made on the device: the caller has the box problem's standard
+// form and the basis the LU of A^T picked (B_index, and N_index in the order of the permutation, :153-160); the
+// engine builds B^-1 and from it y = B^-T c_B, d = c - A^T y, the nonbasic labels and values by the sign of d,
+// b~ = b - A x and x_B = B^-1 b~.  No LU of A_B on the host, no solves, no A x product there.
+ellp_status ellp_engine_create_dual_phase1(int64_t m, int64_t n, const double *A, const double *c, const double *b,
+                                           const uint8_t *bound_kind, const double *lb, const double *ub,
+                                           const int64_t *B_index, const int64_t *N_index, const ellp_opts *opts_in,
+                                           ellp_engine **out, char *errbuf, size_t errlen) {
+    if (errbuf && errlen) errbuf[0] = 0;
+    if (!out) return ELLP_ERR_ARG;
+    *out = nullptr;
+    if (m <= 0 || n <= m || !A || !c || !b || !bound_kind || !lb || !ub || !B_index || !N_index) {
+        set_err(errbuf, errlen, "bad arguments (a nonbasic variable is needed: n > m)");
+        return ELLP_ERR_ARG;
+    }
+    const int64_t nN = n - m;
+    std::vector<double> zeros((size_t)(n > m ? n : m), 0.0);
+    std::vector<uint8_t> Nb((size_t)(nN > 0 ? nN : 1), (uint8_t)ELLP_NB_LOWER);
+    ellp_engine *e = nullptr;
+    ellp_status s = engine_create_impl(ELLP_ENGINE_DUAL, m, n, n, A, c, b, bound_kind, lb, ub, zeros.data(), B_index, m,
+                                       N_index, Nb.data(), nN, zeros.data(), zeros.data(), opts_in, &e, errbuf, errlen, n,
+                                       false);
+    if (s != ELLP_OPTIMAL) return s;
+    auto fail = [&](ellp_status st) {
+        ellp_engine_destroy(e);
+        return st;
+    };
+    if (e->small) {  // k_small keeps no inverse; the point below is made from one all the same
+        launch_refactor(e);
+        if (hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+            hipStreamSynchronize(e->stream) != hipSuccess) {
+            set_err(errbuf, errlen, "HIP error in ellp_engine_create_dual_phase1");
+            return fail(ELLP_ERR_DEVICE);
+        }
+        if (e->h_st->status != ST_RUNNING) return fail(status_message(*e->h_st, errbuf, errlen));
+    }
+    double *c_dev = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&c_dev), sizeof(double) * (size_t)n) != hipSuccess ||
+        hipMemcpyAsync(c_dev, c, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
+        if (c_dev) (void)hipFree(c_dev);
+        set_err(errbuf, errlen, "HIP error in ellp_engine_create_dual_phase1");
+        return fail(ELLP_ERR_DEVICE);
+    }
+    s = dual_point_from_inverse(e, c_dev, 1, N_index, errbuf, errlen);
+    (void)hipStreamSynchronize(e->stream);
+    (void)hipFree(c_dev);
+    if (s != ELLP_OPTIMAL) return fail(s);
+    std::vector<double> y((size_t)m), d((size_t)n);
+    if (hipMemcpy(y.data(), e->y, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(d.data(), e->dd, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_err(errbuf, errlen, "HIP error in ellp_engine_create_dual_phase1");
+        return fail(ELLP_ERR_DEVICE);
+    }
+    const double obj = host_dual_obj(m, n, b, bound_kind, lb, ub, y.data(), d.data());
+    if (hipMemcpy(&e->st->obj, &obj, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return fail(ELLP_ERR_DEVICE);
+    e->h_st->obj = obj;
+    e->need_dleave = true;
+    e->u_valid = false;
+    *out = e;
     return ELLP_OPTIMAL;
 }
 

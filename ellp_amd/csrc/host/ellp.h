@@ -136,8 +136,13 @@ struct DualPhase1 {  // src/solvers/dual/dual_problem.rs:41-46
     StandardForm std_form;
     DualFeasiblePoint point;
     StandardForm orig_std_form;
+    // true: B and N are set (the LU of A^T picked them, :139-160) but y, d, x and the nonbasic labels are still
+    // zero / Lower — ellp_engine_create_dual_phase1 makes them on the device (:162-214)
+    bool point_deferred = false;
     double obj() const { return std_form.dual_obj(point.y, point.d); }
-    static std::optional<DualPhase1> from_problem(Problem prob);  // :89-256
+    // defer_point: leave :162-214 (LU of A_B, three solves, A x) to the device when the engine is of the
+    // explicit-inverse kind (rows > 128) and there is a nonbasic variable
+    static std::optional<DualPhase1> from_problem(Problem prob, bool defer_point = false);  // :89-256
 };
 struct DualPhase2 {  // :69-73
     StandardForm std_form;

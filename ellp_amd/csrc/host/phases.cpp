@@ -146,7 +146,7 @@ std::vector<Index> basic_columns(const std::vector<Basic> &B) {
 }  // namespace
 
 // dual_problem.rs:89-256
-std::optional<DualPhase1> DualPhase1::from_problem(Problem prob) {
+std::optional<DualPhase1> DualPhase1::from_problem(Problem prob, bool defer_point) {
     auto orig_opt = StandardForm::from_problem(std::move(prob));
     if (!orig_opt) return std::nullopt;
     StandardForm orig = std::move(*orig_opt);
@@ -189,7 +189,14 @@ std::optional<DualPhase1> DualPhase1::from_problem(Problem prob) {
     for (Index k = m; k < n; ++k) N.push_back({static_cast<size_t>(perm_cols[static_cast<size_t>(k)]), NonbasicBound::Lower});
 
     DualPhase1 p1;
-    if (!B.empty()) {
+    if (defer_point && m > 128 && !N.empty() && std_form.bounds.size() == static_cast<size_t>(n)) {
+        for (const auto &bd : std_form.bounds)
+            if (bd.kind != Bound::TwoSided && bd.kind != Bound::Fixed) throw EllPPanic("bounds should always be fixed or two-sided");
+        p1.point_deferred = true;
+        p1.point = DualFeasiblePoint{std::vector<double>(static_cast<size_t>(m), 0.0),
+                                     std::vector<double>(std_form.bounds.size(), 0.0),
+                                     Point{std::vector<double>(std_form.bounds.size(), 0.0), std::move(N), std::move(B)}};
+    } else if (!B.empty()) {
         dense::LU A_B_lu(std_form.A.select_columns(basic_columns(B)));
         std::vector<double> y, d;
         duals_for_basis(std_form, B, A_B_lu, y, d);

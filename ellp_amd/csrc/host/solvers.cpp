@@ -237,16 +237,27 @@ SolutionStatus run_resident_dual(ellp_engine *e, std::uint64_t max_iter, Flat &f
 SolverResult DualSimplexSolver::solve(Problem prob) const {
     SolverResult res;
     Problem orig_for_fallback = prob;  // phase_1.into_orig_prob()
-    auto p1 = DualPhase1::from_problem(std::move(prob));
+    auto p1 = DualPhase1::from_problem(std::move(prob), /*defer_point=*/true);
     if (!p1) { res.kind = SolverResult::Infeasible; return res; }
     DualPhase1 phase_1 = std::move(*p1);
     const StandardForm &sf1 = phase_1.std_form;
+    const bool deferred = phase_1.point_deferred;  // rows > 128, N not empty: the device makes y, d, x (:162-214)
     const bool resident = sf1.rows() > 128 && !phase_1.point.point.N.empty() &&
                           sf1.rows() == phase_1.orig_std_form.rows() && sf1.cols() == phase_1.orig_std_form.cols() &&
                           sf1.bounds.size() == phase_1.orig_std_form.bounds.size() && sf1.A.a == phase_1.orig_std_form.A.a;
     EngineHandle eng;
     SolutionStatus s1;
-    if (resident) {
+    if (deferred) {
+        Flat f1 = flatten(sf1, phase_1.point.point);
+        const ellp_opts o = make_opts(max_iter_, engine_);
+        char err[512] = {0};
+        const ellp_status cs = ellp_engine_create_dual_phase1(
+            static_cast<std::int64_t>(sf1.rows()), static_cast<std::int64_t>(sf1.cols()), sf1.A.a.data(), sf1.c.data(),
+            sf1.b.data(), f1.kind.data(), f1.lb.data(), f1.ub.data(), f1.B.data(), f1.N.data(), &o, &eng.e, err,
+            sizeof(err));
+        if (cs != ELLP_OPTIMAL) to_status(cs, err);
+        s1 = run_resident_dual(eng.e, max_iter_, f1, phase_1.point, &res.iters_phase1);
+    } else if (resident) {
         Flat f1 = flatten(sf1, phase_1.point.point);
         const ellp_opts o = make_opts(max_iter_, engine_);
         char err[512] = {0};
@@ -292,6 +303,10 @@ SolverResult DualSimplexSolver::solve(Problem prob) const {
         if (rs != ELLP_OPTIMAL) to_status(rs, err);  // the reference's assertions on the sign of d come back as panics
         s2 = run_resident_dual(eng.e, max_iter_, f2, phase_2.point, &res.iters_phase2);
     } else {
+        if (eng.e) {  // phase 1 ran on a resident engine whose matrix is not phase 2's
+            ellp_engine_destroy(eng.e);
+            eng.e = nullptr;
+        }
         phase_2 = DualPhase2::from_phase1(std::move(phase_1));
         s2 = solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2);
     }

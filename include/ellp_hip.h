@@ -222,6 +222,18 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
 ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *bound_kind, const double *lb,
                                 const double *ub, char *errbuf, size_t errbuf_len);
 
+/* DualPhase1::new's starting point made on the device (src/solvers/dual/dual_problem.rs:162-214).
+ * In: the box problem's standard form (A m x n column-major, c, b, bounds: TwoSided or Fixed only) and the basis
+ * the LU of A^T picked (dual_problem.rs:139-160): B_index[m] and N_index[n-m] in the order of the permutation.
+ * The engine builds B^-1 and from it y = B^-T c_B, d = c - A^T y, each nonbasic variable's label and value by
+ * the sign of d_i (:177-203), b~ = b - A x and x_B = B^-1 b~ (:206-213); read them back with
+ * ellp_engine_read_point.  The result is a dual engine ready for ellp_engine_run (phase 1) and, after it,
+ * ellp_engine_dual_rephase (phase 2).  A bound of another kind is the reference's panic (ELLP_ERR_PANIC). */
+ellp_status ellp_engine_create_dual_phase1(int64_t m, int64_t n, const double *A, const double *c, const double *b,
+                                           const uint8_t *bound_kind, const double *lb, const double *ub,
+                                           const int64_t *B_index, const int64_t *N_index, const ellp_opts *opts,
+                                           ellp_engine **out, char *errbuf, size_t errlen);
+
 /*
  * The dual method's phase-1 -> phase-2 hand-off without leaving HBM (SURVEY.md §8 f2;
  * DualPhase2::from(phase_1), dual_problem.rs:258-404) for the common case that the box problem of phase 1

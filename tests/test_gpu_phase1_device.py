@@ -74,3 +74,68 @@ def test_phase1_arrays_made_on_the_device(m, n, mixed):
     assert stats.iters == stats_r.iters
     np.testing.assert_array_equal(fp.B, ref_fp.B)
     np.testing.assert_allclose(fp.x, ref_fp.x, rtol=0, atol=1e-9 * (1 + np.abs(ref_fp.x).max()))
+
+
+# ---- the dual's phase-1 point (ellp_engine_create_dual_phase1; dual_problem.rs:162-214)
+@pytest.mark.parametrize("m,n,pipeline", [(150, 300, 1), (200, 500, 1), (40, 90, 0)])
+def test_dual_phase1_point_made_on_the_device(m, n, pipeline):
+    """y = B^-T c_B, d = c - A^T y, labels / values by the sign of d, x_B = B^-1 (b - A x) from the basis the
+    LU of A^T picked: against the oracle's construction (LU solves), then both engines run phase 1.  The last
+    case is a small LP: the point is made from an explicit inverse, the loop then runs in the persistent kernel."""
+    E = _E()
+    d1, err = eo.dual_phase1(eo.synth_problem(20260301, m, n))
+    assert d1 is not None and not err
+    v = d1.view()
+    assert v.n_c == v.n and v.nN > 0
+    opts = E.default_opts(max_iter=None, pipeline=pipeline)
+    eng = E.Engine.dual_phase1(v.m, v.n, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.B, v.N[:v.nN], opts)
+    eng.read_point()
+    fp = eng.fp
+    np.testing.assert_array_equal(fp.B, v.B)
+    np.testing.assert_array_equal(fp.N, v.N[:v.nN])
+    sc = 1 + max(np.abs(v.x).max(), np.abs(v.y).max(), np.abs(v.d).max())
+    np.testing.assert_allclose(fp.y, v.y, rtol=0, atol=1e-10 * sc)
+    np.testing.assert_allclose(fp.d, v.d, rtol=0, atol=1e-10 * sc)
+    # labels: by the sign of d, which is only decided where |d| is above roundoff
+    Nidx = v.N[:v.nN]
+    clear = np.abs(v.d[Nidx]) > 1e-9 * sc
+    np.testing.assert_array_equal(fp.Nb[clear], v.Nb[:v.nN][clear])
+    if clear.all():
+        np.testing.assert_allclose(fp.x, v.x, rtol=0, atol=1e-9 * sc)
+    ref_fp = E.FlatProblem(v.m, v.n, v.n_c, v.A, v.c, v.b, v.kind, v.lb, v.ub, v.x, v.B, v.N[:v.nN], v.Nb[:v.nN], v.y, v.d)
+    ref = E.Engine(E.ENGINE_DUAL, ref_fp, opts)
+    st_r, stats_r, _ = ref.run(1 << 40)
+    ref.read_point()
+    ref.close()
+    st, stats, msg = eng.run(1 << 40)
+    eng.read_point()
+    eng.close()
+    assert st == st_r == E.OPTIMAL, msg
+    obj = lambda f: eo_dual_obj(v, f)
+    assert abs(obj(fp) - obj(ref_fp)) < 1e-8 * (1 + abs(obj(ref_fp)))
+    if clear.all():
+        assert stats.iters == stats_r.iters
+        np.testing.assert_array_equal(fp.B, ref_fp.B)
+
+
+def eo_dual_obj(v, f):
+    """dual_simplex_solver.rs:184 on a FlatProblem's y and d"""
+    o = float(np.dot(v.b, f.y))
+    for i in range(v.n_c):
+        k, di = int(v.kind[i]), float(f.d[i])
+        if k == 1: o += v.lb[i] * di
+        elif k == 2: o += v.ub[i] * di
+        elif k == 3: o += (v.lb[i] if di > 0 else v.ub[i]) * di
+        elif k == 4: o += v.lb[i] * di
+    return o
+
+
+def test_dual_phase1_refuses_other_bounds():
+    E = _E()
+    d1, _ = eo.dual_phase1(eo.synth_problem(20260301, 150, 300))
+    v = d1.view()
+    kind = np.array(v.kind).copy()
+    kind[int(v.N[0])] = 1                     # Lower: "bounds should always be fixed or two-sided"
+    with pytest.raises(E.EllpHipError) as ei:
+        E.Engine.dual_phase1(v.m, v.n, v.A, v.c, v.b, kind, v.lb, v.ub, v.B, v.N[:v.nN], E.default_opts(pipeline=1))
+    assert "fixed or two-sided" in str(ei.value)
