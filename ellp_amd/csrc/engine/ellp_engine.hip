@@ -52,6 +52,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "ellp_hip.h"
@@ -2300,7 +2301,16 @@ struct RcclApi {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// a stream and the pinned status buffers of an engine; pooled per process (host_pool)
+struct HostSet {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevState *h_st = nullptr;
+    DevState *h_look = nullptr;
+};
+
 struct ellp_engine {
+    HostSet host_set;
     int kind = 0;
     int64_t m = 0, n = 0, n_c = 0, nN = 0, ld = 0;
     double eps = 1e-10;
@@ -2365,6 +2375,10 @@ struct ellp_engine {
     bool small = false;      // run() uses k_small
     bool w_valid = true;     // the explicit inverse W (not kept by k_small) matches A_B
     size_t small_lds = 0;
+    char *slab = nullptr;  // see dmalloc
+    size_t slab_size = 0, slab_used = 0;
+    unsigned long long *small_stamps = nullptr;  // ELLP_SMALL_STAMPS: per-phase tick sums of k_small, printed at destroy
+    int small_nt = SMALL_THREADS;  // workgroup size of k_small for this LP (small_threads)
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
     int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
@@ -2424,15 +2438,48 @@ void set_err(char *errbuf, size_t len, const char *fmt, ...) {
         }                                                                                         \
     } while (0)
 
+// Device memory of an engine.  Arrays up to 512 KB come out of one 6 MB slab (an engine has ~45 arrays; for a
+// small LP their hipMalloc / hipFree calls were 3 of the 4.8 ms of an AFIRO solve), larger ones are allocations
+// of their own.  Everything is released by ellp_engine_destroy.
 template <typename T>
 hipError_t dmalloc(ellp_engine *e, T **p, size_t count) {
+    const size_t bytes = ((count ? count : 1) * sizeof(T) + 255) / 256 * 256;
+    if (bytes <= (512u << 10)) {
+        if (!e->slab) {
+            void *sl = nullptr;
+            if (hipMalloc(&sl, 6u << 20) == hipSuccess) {
+                e->slab = static_cast<char *>(sl);
+                e->slab_size = 6u << 20;
+                e->slab_used = 0;
+                e->allocs.push_back(sl);
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (e->slab && e->slab_used + bytes <= e->slab_size) {
+            *p = reinterpret_cast<T *>(e->slab + e->slab_used);
+            e->slab_used += bytes;
+            return hipSuccess;
+        }
+    }
     void *q = nullptr;
-    hipError_t rc = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+    hipError_t rc = hipMalloc(&q, bytes);
     if (rc == hipSuccess) {
         e->allocs.push_back(q);
         *p = static_cast<T *>(q);
     }
     return rc;
+}
+
+// `neu` (a hipMalloc of its own) takes the place of the engine array `old`
+inline void replace_alloc(ellp_engine *e, void *old, void *neu) {
+    for (auto &p : e->allocs)
+        if (p == old) {
+            (void)hipFree(p);
+            p = neu;
+            return;
+        }
+    e->allocs.push_back(neu);  // `old` lives in the slab
 }
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -3070,6 +3117,55 @@ int ellp_hip_device_count(void) {
     return n;
 }
 
+// Streams and pinned status buffers outlive engines: hipStreamCreate + hipStreamDestroy + hipHostMalloc/Free were
+// 3 of the 4.8 ms of an AFIRO solve (rocprofv3 --hip-trace: ~1.4 ms per stream call).  An engine takes a set for
+// its device from this process-wide pool and gives it back, drained, when it is destroyed.
+struct HostPool {
+    std::mutex mu;
+    std::vector<HostSet> free_sets;
+};
+static HostPool &host_pool() {
+    static HostPool *p = new HostPool;  // never destroyed: the HIP runtime may be gone before static destructors run
+    return *p;
+}
+static hipError_t host_set_acquire(int device, HostSet *out) {
+    {
+        HostPool &hp = host_pool();
+        std::lock_guard<std::mutex> g(hp.mu);
+        for (size_t k = 0; k < hp.free_sets.size(); ++k)
+            if (hp.free_sets[k].device == device) {
+                *out = hp.free_sets[k];
+                hp.free_sets.erase(hp.free_sets.begin() + (long)k);
+                return hipSuccess;
+            }
+    }
+    HostSet hs;
+    hs.device = device;
+    hipError_t rc = hipStreamCreateWithFlags(&hs.stream, hipStreamNonBlocking);
+    if (rc != hipSuccess) return rc;
+    rc = hipHostMalloc(reinterpret_cast<void **>(&hs.h_st), sizeof(DevState), hipHostMallocDefault);
+    if (rc == hipSuccess) rc = hipHostMalloc(reinterpret_cast<void **>(&hs.h_look), 2 * sizeof(DevState), hipHostMallocDefault);
+    if (rc != hipSuccess) {
+        if (hs.h_st) (void)hipHostFree(hs.h_st);
+        (void)hipStreamDestroy(hs.stream);
+        return rc;
+    }
+    *out = hs;
+    return hipSuccess;
+}
+static void host_set_release(const HostSet &hs) {
+    if (!hs.stream) return;
+    HostPool &hp = host_pool();
+    std::lock_guard<std::mutex> g(hp.mu);
+    if (hp.free_sets.size() < 16) {
+        hp.free_sets.push_back(hs);
+        return;
+    }
+    (void)hipHostFree(hs.h_st);
+    (void)hipHostFree(hs.h_look);
+    (void)hipStreamDestroy(hs.stream);
+}
+
 void ellp_engine_destroy(ellp_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
@@ -3085,19 +3181,43 @@ void ellp_engine_destroy(ellp_engine *e) {
             }
     }
 #endif
+    if (e->small_stamps) {
+        unsigned long long t[10] = {0};
+        if (hipMemcpy(t, e->small_stamps, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[8] > 0) {
+            static const char *nm[8] = {"leaving row", "copy A_B", "LU", "BTRAN", "pricing", "entering fold", "FTRAN",
+                                        "ratio test + updates"};
+            fprintf(stderr, "k_small m=%lld nN=%lld threads=%d, us per iteration over %llu iterations:", (long long)e->m,
+                    (long long)e->nN, e->small_nt, t[8]);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.2f;", nm[k], (double)t[k] / 100.0 / (double)t[8]);
+            double tot = 0.0;
+            for (int k = 0; k < 8; ++k) tot += (double)t[k];
+            fprintf(stderr, " total %.2f; shader clock %.0f MHz\n", tot / 100.0 / (double)t[8], (double)t[9] / (tot / 100.0));
+        }
+    }
     e->stream = e->own_stream;
     if (e->comm && e->rccl) (void)e->rccl->CommDestroy(e->comm);
     for (void *p : e->ipc_opened) (void)hipIpcCloseMemHandle(p);
     if (e->mbox) (void)hipFree(e->mbox);
     if (e->mflags) (void)hipFree(e->mflags);
     for (void *p : e->allocs) (void)hipFree(p);
-    if (e->h_st) (void)hipHostFree(e->h_st);
-    if (e->h_look) (void)hipHostFree(e->h_look);
     for (auto ev : e->look_ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    host_set_release(e->host_set);
     delete e;
+}
+
+// the instantiation of k_small for an engine kind and a workgroup size
+static const void *small_kernel(int kind, int nt) {
+    if (kind == ELLP_ENGINE_PRIMAL) {
+        if (nt == 64) return reinterpret_cast<const void *>(&k_small<0, 64>);
+        if (nt == 128) return reinterpret_cast<const void *>(&k_small<0, 128>);
+        return reinterpret_cast<const void *>(&k_small<0, 256>);
+    }
+    if (nt == 64) return reinterpret_cast<const void *>(&k_small<1, 64>);
+    if (nt == 128) return reinterpret_cast<const void *>(&k_small<1, 128>);
+    return reinterpret_cast<const void *>(&k_small<1, 256>);
 }
 
 // n_explicit: columns of A the caller passes; columns n_explicit .. n-1 (m of them, or none) are the
@@ -3194,8 +3314,11 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     } while (0)
 
     ECHK(hipSetDevice(dev));
-    ECHK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    ECHK(host_set_acquire(dev, &e->host_set));
+    e->stream = e->host_set.stream;
     e->own_stream = e->stream;
+    e->h_st = e->host_set.h_st;
+    e->h_look = e->host_set.h_look;
     const int64_t ld = e->ld;
     const int64_t nNa = n_N > 0 ? n_N : 1;
     // geometry
@@ -3311,7 +3434,6 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     ECHK(dmalloc(e, &e->T, (size_t)(m * ld)));
     ECHK(hipMemsetAsync(e->T, 0, sizeof(double) * (size_t)(m * ld), e->stream));
     ECHK(dmalloc(e, &e->st, 1));
-    ECHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_st), sizeof(DevState), hipHostMallocDefault));
     if (kind == ELLP_ENGINE_DUAL) {
         ECHK(dmalloc(e, &e->y, (size_t)ld));
         ECHK(dmalloc(e, &e->dd, (size_t)n_c));
@@ -3428,11 +3550,18 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         }
         e->small = wanted && e->small_lds > 0;
         if (e->small) {
-            hipError_t ra = e->kind == ELLP_ENGINE_PRIMAL
-                                ? hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small<0>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->small_lds)
-                                : hipFuncSetAttribute(reinterpret_cast<const void *>(&k_small<1>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->small_lds);
+            int nt = small_threads(m, n_N);
+            if (const char *ev = getenv("ELLP_SMALL_NT")) {  // measurement: force a workgroup size that still has a thread per row
+                const int v = atoi(ev);
+                if ((v == 64 || v == 128 || v == 256) && v >= m) nt = v;
+            }
+            e->small_nt = nt;
+            if (getenv("ELLP_SMALL_STAMPS") && !e->small_stamps) {
+                if (dmalloc(e, &e->small_stamps, 16) == hipSuccess) (void)hipMemsetAsync(e->small_stamps, 0, 128, e->stream);
+                else e->small_stamps = nullptr;
+            }
+            const void *fn = small_kernel(e->kind, nt);
+            hipError_t ra = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->small_lds);
             if (ra != hipSuccess) {
                 (void)hipGetLastError();
                 e->small = false;  // the large engine handles it
@@ -3550,10 +3679,12 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
         a.nch = (int)((e->nN + 63) / 64);
         a.eps = e->eps;
         a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
-        if (e->kind == ELLP_ENGINE_PRIMAL)
-            hipLaunchKernelGGL(k_small<0>, dim3(1), dim3(SMALL_THREADS), e->small_lds, e->stream, a);
-        else
-            hipLaunchKernelGGL(k_small<1>, dim3(1), dim3(SMALL_THREADS), e->small_lds, e->stream, a);
+        a.stamps = e->small_stamps;
+        {
+            void *kargs[] = {&a};
+            HIPCHK(hipLaunchKernel(small_kernel(e->kind, e->small_nt), dim3(1), dim3((unsigned)e->small_nt), kargs,
+                                   e->small_lds, e->stream));
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
@@ -3645,8 +3776,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             // maintenance request of the drift monitor — is a few no-op launches (every kernel returns at
             // once when status != RUNNING).  Iterations are counted on the device afterwards.
             if (can_look_ahead && e->maint_chain == 0) {
-                if (!e->h_look) {
-                    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&e->h_look), 2 * sizeof(DevState), hipHostMallocDefault));
+                if (!e->look_ev[0]) {
                     HIPCHK(hipEventCreateWithFlags(&e->look_ev[0], hipEventDisableTiming));
                     HIPCHK(hipEventCreateWithFlags(&e->look_ev[1], hipEventDisableTiming));
                 }
@@ -4165,11 +4295,7 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
         hipLaunchKernelGGL(k_permute_cols, dim3((unsigned)nN), dim3(256), 0, e->stream, e->A_N, A2, perm_dev, ld);
         DCHK(hipMemcpyAsync(e->N_index, Nsorted.data(), sizeof(int64_t) * (size_t)nN, hipMemcpyHostToDevice, e->stream));
         DCHK(hipStreamSynchronize(e->stream));
-        for (auto &p : e->allocs)
-            if (p == e->A_N) {
-                (void)hipFree(p);
-                p = A2;
-            }
+        replace_alloc(e, e->A_N, A2);
         e->A_N = A2;
     }
     // ---- new costs, right-hand side, bounds
@@ -4377,11 +4503,7 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
     if (nloc > 0)
         HIPCHK(hipMemcpy(loc, e->A_N + a0 * ld, sizeof(double) * (size_t)(ld * nloc), hipMemcpyDeviceToDevice));
     // release the full A_N: it is one of e->allocs
-    for (auto &p : e->allocs)
-        if (p == e->A_N) {
-            (void)hipFree(p);
-            p = loc;
-        }
+    replace_alloc(e, e->A_N, loc);
     e->A_N_store = loc;
     e->A_N = loc - a0 * ld;  // virtual base: only [own0, own1) may be dereferenced
     e->own0 = a0;

@@ -93,6 +93,7 @@ int ellp_solve(const ellp_problem *p, int solver, uint64_t max_iter, const ellp_
         eo.refactor_period = opts->refactor_period;
         eo.btran_mode = opts->btran_mode;
         eo.poll_interval = opts->poll_interval;
+        eo.pipeline = opts->pipeline;
     }
     const std::optional<std::uint64_t> mi =
         max_iter == ELLP_MAX_ITER_NONE ? std::nullopt : std::optional<std::uint64_t>(max_iter);

@@ -55,6 +55,7 @@ ellp_opts make_opts(std::uint64_t max_iter, const EngineOptions &e) {
     o.refactor_period = e.refactor_period;
     o.btran_mode = e.btran_mode;
     o.poll_interval = e.poll_interval;
+    o.pipeline = e.pipeline;
     return o;
 }
 

@@ -100,3 +100,30 @@ def check_result(fx, status_name, obj, x, abs_eps=1e-8, rel_eps=1e-6):
         assert abs(obj - e) < abs_eps or abs(obj / e - 1.0) < rel_eps, f"obj: {obj}, expected: {e}"
     else:
         raise AssertionError(chk)
+
+
+def collect_results(q, procs, world, timeout):
+    """One result per rank from the queue of a spawned world; gives up as soon as a rank has died without
+    reporting (a crashed child must not cost the whole timeout — on the GPU box that is minutes of budget)."""
+    import queue as _queue
+    import time as _time
+    results, deadline = [], _time.monotonic() + timeout
+    while len(results) < world:
+        try:
+            results.append(q.get(timeout=1.0))
+            continue
+        except _queue.Empty:
+            pass
+        if _time.monotonic() > deadline:
+            raise TimeoutError(f"{len(results)} of {world} ranks reported within {timeout} s")
+        dead = [p.exitcode for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+        if dead:
+            _time.sleep(1.0)  # what the survivors still had in flight
+            while len(results) < world:
+                try:
+                    results.append(q.get(timeout=0.2))
+                except _queue.Empty:
+                    break
+            if len(results) < world:
+                raise RuntimeError(f"a rank died (exit codes {dead}) before reporting; {len(results)} of {world} results")
+    return results

@@ -6,6 +6,8 @@ import socket
 
 import numpy as np
 import pytest
+
+from helpers import collect_results
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -63,7 +65,7 @@ def test_exchange_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, seg, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = collect_results(q, procs, world, 120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -174,7 +176,7 @@ def test_pack_selection_on_gathered_packs_world2():
     procs = [ctx.Process(target=_select_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
+    results = collect_results(q, procs, world, 180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -7,6 +7,8 @@ import socket
 import numpy as np
 import pytest
 
+from helpers import collect_results
+
 pytestmark = pytest.mark.gpu
 
 
@@ -135,7 +137,7 @@ def test_sharded_engine_takes_the_same_pivots_world2():
         p.daemon = True
         p.start()
     try:
-        results = [q.get(timeout=400) for _ in range(world)]
+        results = collect_results(q, procs, world, 400)
     except Exception:
         for p in procs:
             if p.is_alive():
