@@ -2282,6 +2282,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
     }
 }
 
+#include "ellp_gemm.inc"
 #include "ellp_lagged.inc"
 #include "ellp_shard.inc"
 #include "ellp_rebuild.inc"
@@ -2737,9 +2738,15 @@ void launch_refresh(ellp_engine *e) {
     Prof p(e, ELLP_K_REFACTOR);
     GemmArgs a{e->W, e->W2, e->A_B, e->T, e->resid, e->st, e->m, e->ld};
     const unsigned nt = (unsigned)((e->m + 127) / 128);
-    hipLaunchKernelGGL(k_gemm128<0>, dim3(nt, nt), dim3(256), 0, e->stream, a);
+    static const bool valu = [] {  // measurement: ELLP_GEMM=valu runs round 1's vector-ALU GEMM
+        const char *v = getenv("ELLP_GEMM");
+        return v && strcmp(v, "valu") == 0;
+    }();
+    if (valu) hipLaunchKernelGGL(k_gemm128<0>, dim3(nt, nt), dim3(256), 0, e->stream, a);
+    else hipLaunchKernelGGL(k_gemm_mfma<0>, dim3(nt, nt), dim3(512), 0, e->stream, a);
     hipLaunchKernelGGL(k_resid_reduce, dim3(1), dim3(256), 0, e->stream, a, (int)(nt * nt));
-    hipLaunchKernelGGL(k_gemm128<1>, dim3(nt, nt), dim3(256), 0, e->stream, a);
+    if (valu) hipLaunchKernelGGL(k_gemm128<1>, dim3(nt, nt), dim3(256), 0, e->stream, a);
+    else hipLaunchKernelGGL(k_gemm_mfma<1>, dim3(nt, nt), dim3(512), 0, e->stream, a);
     hipLaunchKernelGGL(k_copy_to_other, dim3(1024), dim3(256), 0, e->stream, a);
     hipLaunchKernelGGL(k_refresh_finish, dim3(1), dim3(1), 0, e->stream, a);
     e->refreshes += 1;
