@@ -167,6 +167,36 @@ __device__ __forceinline__ double wave_min(double v) {
     return v;
 }
 
+// ---- wave-wide max / min without the LDS crossbar (`__shfl_xor` is ds_bpermute on this target: ~100 cycles
+// per step): four DPP butterfly steps inside each row of 16 lanes, then the four rows through readlane.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    return __hiloint2double(dpp_i32<CTRL>(__double2hiint(v)), dpp_i32<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// v must not be NaN
+__device__ __forceinline__ double wave_allmax_dpp(double v) {
+    v = fmax(v, dpp_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_f64<0x141>(v));  // row_half_mirror
+    v = fmax(v, dpp_f64<0x140>(v));  // row_mirror
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ int wave_allmin_dpp(int v) {
+    v = min(v, dpp_i32<0xB1>(v));
+    v = min(v, dpp_i32<0x4E>(v));
+    v = min(v, dpp_i32<0x141>(v));
+    v = min(v, dpp_i32<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // ------------------------------------------------------------------ pricing output / exchange buffer
 // The pricing kernels write their per-column and per-block results into ONE buffer laid out in
 // `world` equal segments, one per rank (world = 1 on a single GPU):
