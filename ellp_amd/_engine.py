@@ -147,6 +147,8 @@ def lib():
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ellp_shard_pack_doubles.restype = C.c_int64
     L.ellp_shard_pack_doubles.argtypes = [C.c_int64]
+    L.ellp_hip_lu_transposed.restype = C.c_int
+    L.ellp_hip_lu_transposed.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
     L.ellp_engine_shard_info.restype = C.c_int
     L.ellp_engine_shard_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     _lib = L
@@ -166,6 +168,20 @@ def qr_transposed(A, device=-1):
     if s != OPTIMAL:
         raise EllpHipError(s, err.value.decode())
     return piv, rd
+
+
+def lu_transposed(A, device=-1):
+    """LU with partial pivoting of A^T on the device (dual_problem.rs:141).  A: (m, nv) array, nv >= m.
+    Returns (pivots, U_ii), both of length m."""
+    A = np.asfortranarray(A, dtype=np.float64)
+    m, nv = A.shape
+    piv = np.zeros(m, dtype=np.int64)
+    ud = np.zeros(m, dtype=np.float64)
+    err = C.create_string_buffer(512)
+    s = lib().ellp_hip_lu_transposed(m, nv, A.ctypes.data_as(C.c_void_p), _p(piv), _p(ud), int(device), err, 512)
+    if s != OPTIMAL:
+        raise EllpHipError(s, err.value.decode())
+    return piv, ud
 
 
 def shard_pack_doubles(ld):

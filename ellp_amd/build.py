@@ -11,7 +11,8 @@ ROOT = os.path.dirname(HERE)
 INCLUDE = os.path.join(ROOT, "include")
 
 ENGINE_SRC = [os.path.join(HERE, "csrc", "engine", "ellp_engine.hip"),
-              os.path.join(HERE, "csrc", "engine", "ellp_qr.hip")]
+              os.path.join(HERE, "csrc", "engine", "ellp_qr.hip"),
+              os.path.join(HERE, "csrc", "engine", "ellp_lu.hip")]
 ENGINE_LIB = os.path.join(HERE, "libellp_hip.so")
 HOST_DIR = os.path.join(HERE, "csrc", "host")
 HOST_LIB = os.path.join(HERE, "libellp_host.so")

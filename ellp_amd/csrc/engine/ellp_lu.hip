@@ -1,0 +1,236 @@
+// ellp_lu.hip — LU with partial pivoting of A^T on the device (the basis of dual phase 1).
+//
+// The reference picks the starting basis of dual phase 1 from `std_form.A.transpose().lu()`
+// (src/solvers/dual/dual_problem.rs:139-160): all it consumes is the row permutation (which columns of A become
+// basic) and the diagonal of U (`< EPS` -> panic).  That is n·m² flop on one host core — 56 GFLOP and about a
+// minute at config 3's shape, a quarter of an hour at config 5's — in front of a simplex loop that takes seconds.
+//
+// Same algorithm as ellp_amd/csrc/host/dense.h LU / oracle lu_factor_inplace (pivot = FIRST entry of maximal
+// modulus in the column; a zero pivot column is skipped; multipliers a·(1/diag); trailing update
+// c_k[r] = (-c_k[i])·c_i[r] + c_k[r], skipped for a zero c_k[i]), and every stored number is BITWISE the host
+// loop's: an entry M[r,k] receives its updates in the order of the steps whatever thread makes them, each one
+// a separately rounded multiply and add (compiled with -ffp-contract=off).
+//
+// M = A^T (nv x m) is walked through A's own column-major storage: row r of M is column r of A, m contiguous
+// doubles — so a row swap moves two contiguous rows, the trailing update of a row is a contiguous stream, and
+// the matrix needs no transposition.  One launch per elimination step: each wave updates one row (its
+// multiplier from the pivot row parked in a scratch buffer by the previous launch), reports |M[r, i+1]| for
+// the next pivot search, and the block that finishes last folds the per-block candidates (first maximum by
+// row), parks the next pivot row and the row it displaces, and records the pivot — rows are swapped lazily:
+// the displaced row is read from its parked copy by the wave that owns the pivot's old position.
+// Right-looking and unblocked: the whole trailing matrix is read and written once per step (about
+// 16·nv·m²/2 bytes in all: 0.3 TB at config 3's shape); a blocked variant would divide that by the panel width.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "ellp_hip.h"
+
+namespace {
+
+struct LuState {
+    long long piv;     // pivot row of the step the next launch eliminates
+    double diag;       // its entry in the pivot column
+    int32_t skip;      // diag == 0: the column is skipped (dense.h: `continue`)
+    uint32_t ticket;   // blocks that have finished in the current launch
+};
+struct LuCand {
+    double v;
+    long long r;
+};
+
+constexpr int LU_RPB = 4;  // rows (= waves) per block
+
+// Launch `i` (i = -1: nothing to eliminate, only the search of column 0):
+//   block 0            writes the pivot row of step i to position i (the other half of the lazy swap)
+//   block 1 + b, wave w eliminates row r = i + 1 + 4 b + w with the pivot of step i and reports |M[r, i+1]|
+//   the last block     folds the candidates -> pivot of step i+1, parks rows piv and i+1
+__global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t nv, int64_t i, double *prow, double *irow,
+                                                  LuCand *cands, LuState *st, int64_t *pivot_out, double *udiag_out) {
+    __shared__ double s_v[LU_RPB];
+    __shared__ long long s_r[LU_RPB];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long piv = st->piv;
+    const bool skip = i < 0 || st->skip != 0;
+    const int64_t nxt = i + 1;  // the column searched for the next step
+    double cv = -1.0;
+    long long cr = -1;
+    if (blockIdx.x == 0) {
+        if (!skip && piv != i)
+            for (int64_t k = tid; k < m; k += 256) M[i * m + k] = prow[k];
+    } else {
+        const int64_t r = nxt + (int64_t)(blockIdx.x - 1) * LU_RPB + wave;
+        if (r < nv) {
+            double *dst = M + r * m;
+            double first = 0.0;  // M[r, i+1] after this step
+            if (!skip) {
+                const bool moved = r == piv;  // this position receives the row the pivot displaced
+                const double *src = moved ? irow : dst;
+                const double inv_diag = 1.0 / st->diag;
+                const double l = __dmul_rn(src[i], inv_diag);
+                if (moved)
+                    for (int64_t k = lane; k < i; k += 64) dst[k] = src[k];
+                if (lane == 0) dst[i] = l;
+                for (int64_t k = nxt + lane; k < m; k += 64) {
+                    const double f = -prow[k];
+                    double val;
+                    if (f == 0.0) {
+                        val = src[k];
+                        if (moved) dst[k] = val;
+                    } else {
+                        val = __dadd_rn(__dmul_rn(f, l), src[k]);
+                        dst[k] = val;
+                    }
+                    if (k == nxt) first = val;
+                }
+            } else if (nxt < m && lane == 0) {
+                first = dst[nxt];
+            }
+            if (nxt < m) {
+                first = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(first)),
+                                         __builtin_amdgcn_readfirstlane(__double2loint(first)));
+                double v = fabs(first);
+                if (v != v) v = (r == nxt) ? INFINITY : -1.0;  // `v > best` is false for a NaN: only the diagonal can carry one
+                cv = v;
+                cr = r;
+            }
+        }
+    }
+    if (nxt >= m) return;  // the last elimination: nothing to search
+    if (lane == 0) {
+        s_v[wave] = cv;
+        s_r[wave] = cr;
+    }
+    __threadfence();  // this thread's part of the rows is in L2 before the block takes its ticket
+    __syncthreads();
+    if (tid == 0) {
+        double bv = s_v[0];
+        long long br = s_r[0];
+        for (int w = 1; w < LU_RPB; ++w)
+            if (s_r[w] >= 0 && (br < 0 || s_v[w] > bv || (s_v[w] == bv && s_r[w] < br))) {
+                bv = s_v[w];
+                br = s_r[w];
+            }
+        cands[blockIdx.x] = LuCand{bv, br};
+        __threadfence();
+        const uint32_t t = atomicAdd(&st->ticket, 1u);
+        s_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the block that finished last: everything the other blocks wrote is visible after this fence
+    __threadfence();
+    double bv = -1.0;
+    long long br = -1;
+    for (unsigned b = tid; b < gridDim.x; b += 256) {
+        const LuCand c = cands[b];
+        if (c.r >= 0 && (br < 0 || c.v > bv || (c.v == bv && c.r < br))) {
+            bv = c.v;
+            br = c.r;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o);
+        const long long orr = __shfl_xor(br, o);
+        if (orr >= 0 && (br < 0 || ov > bv || (ov == bv && orr < br))) {
+            bv = ov;
+            br = orr;
+        }
+    }
+    if (lane == 0) {
+        s_v[wave] = bv;
+        s_r[wave] = br;
+    }
+    __syncthreads();
+    bv = s_v[0];
+    br = s_r[0];
+    for (int w = 1; w < LU_RPB; ++w)
+        if (s_r[w] >= 0 && (br < 0 || s_v[w] > bv || (s_v[w] == bv && s_r[w] < br))) {
+            bv = s_v[w];
+            br = s_r[w];
+        }
+    // br >= 0: row nxt itself is always a candidate (nv >= m)
+    const double diag = M[br * m + nxt];
+    for (int64_t k = tid; k < m; k += 256) {
+        prow[k] = M[br * m + k];
+        irow[k] = M[nxt * m + k];
+    }
+    if (tid == 0) {
+        st->piv = br;
+        st->diag = diag;
+        st->skip = diag == 0.0 ? 1 : 0;
+        st->ticket = 0;
+        pivot_out[nxt] = diag == 0.0 ? nxt : br;  // a skipped column appends no transposition (dense.h)
+        udiag_out[nxt] = diag;
+    }
+}
+
+void set_err(char *errbuf, size_t len, const char *msg, hipError_t e) {
+    if (errbuf && len) snprintf(errbuf, len, "%s: %s", msg, hipGetErrorString(e));
+}
+
+}  // namespace
+
+extern "C" ellp_status ellp_hip_lu_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out,
+                                              double *udiag_out, int device, char *errbuf, size_t errlen) {
+    if (errbuf && errlen) errbuf[0] = 0;
+    if (m < 0 || nv < 0 || (m > 0 && nv > 0 && (!A || !pivot_out || !udiag_out))) return ELLP_ERR_ARG;
+    if (nv < m) {
+        if (errbuf && errlen) snprintf(errbuf, errlen, "ellp_hip_lu_transposed needs nv >= m (every column of A^T gets a pivot row)");
+        return ELLP_ERR_ARG;
+    }
+    if (m == 0) return ELLP_OPTIMAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        if (errbuf && errlen) snprintf(errbuf, errlen, "no HIP device available");
+        return ELLP_ERR_DEVICE;
+    }
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return ELLP_ERR_DEVICE;
+    double *dM = nullptr, *prow = nullptr, *irow = nullptr, *udiag = nullptr;
+    int64_t *piv = nullptr;
+    LuCand *cands = nullptr;
+    LuState *st = nullptr;
+    hipStream_t stream = nullptr;
+    hipError_t rc = hipSuccess;
+    auto cleanup = [&] {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        (void)hipFree(dM); (void)hipFree(prow); (void)hipFree(irow); (void)hipFree(udiag); (void)hipFree(piv); (void)hipFree(cands); (void)hipFree(st);
+    };
+#define LCHK(expr)                                      \
+    do {                                                \
+        rc = (expr);                                    \
+        if (rc != hipSuccess) {                         \
+            set_err(errbuf, errlen, #expr, rc);         \
+            cleanup();                                  \
+            return ELLP_ERR_DEVICE;                     \
+        }                                               \
+    } while (0)
+    const unsigned max_blocks = (unsigned)((nv + LU_RPB - 1) / LU_RPB) + 1;
+    LCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&dM), sizeof(double) * (size_t)(m * nv)));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&prow), sizeof(double) * (size_t)m));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&irow), sizeof(double) * (size_t)m));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&udiag), sizeof(double) * (size_t)m));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&piv), sizeof(int64_t) * (size_t)m));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&cands), sizeof(LuCand) * (size_t)max_blocks));
+    LCHK(hipMalloc(reinterpret_cast<void **>(&st), sizeof(LuState)));
+    LCHK(hipMemcpyAsync(dM, A, sizeof(double) * (size_t)(m * nv), hipMemcpyHostToDevice, stream));
+    LCHK(hipMemsetAsync(st, 0, sizeof(LuState), stream));
+    for (int64_t i = -1; i < m; ++i) {
+        const int64_t rows = nv - i - 1;
+        const unsigned grid = (unsigned)((rows + LU_RPB - 1) / LU_RPB) + 1;
+        hipLaunchKernelGGL(k_lut_step, dim3(grid), dim3(256), 0, stream, dM, m, nv, i, prow, irow, cands, st, piv, udiag);
+    }
+    LCHK(hipGetLastError());
+    LCHK(hipMemcpyAsync(pivot_out, piv, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, stream));
+    LCHK(hipMemcpyAsync(udiag_out, udiag, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, stream));
+    LCHK(hipStreamSynchronize(stream));
+#undef LCHK
+    cleanup();
+    return ELLP_OPTIMAL;
+}

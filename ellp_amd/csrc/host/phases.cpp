@@ -1,8 +1,10 @@
 // phases.cpp — phase construction (once-per-solve host setup):
 //   src/solvers/primal/primal_problem.rs:80-291, src/solvers/dual/dual_problem.rs:89-404
 #include <cmath>
+#include <cstdlib>
 
 #include "ellp.h"
+#include "ellp_hip.h"
 
 namespace ellp {
 
@@ -177,12 +179,42 @@ std::optional<DualPhase1> DualPhase1::from_problem(Problem prob, bool defer_poin
     StandardForm std_form = std::move(*sf_opt);
 
     const Index n = std_form.A.cols, m = std_form.A.rows;
-    dense::LU lu_t(std_form.A.transpose());
-    if (lu_t.any_small_diag(EPS)) throw EllPPanic("should always have a basis available");
+    // `std_form.A.transpose().lu()` (:141), of which :143-160 use the diagonal of U and the row permutation.
+    // From 2^20 entries on (or with ELLP_LU_DEVICE=1) it runs on the device, bitwise the same numbers
+    // (ellp_hip_lu_transposed); the host loop is n m^2 flop on one core.
+    dense::PermutationSequence lu_p;
+    bool small_diag = false;
+    {
+        const char *force = std::getenv("ELLP_LU_DEVICE");
+        const bool want_device = n >= m && m > 0 && (force ? force[0] == '1' : (m * n >= (Index)1 << 20));
+        bool done = false;
+        if (want_device) {
+            std::vector<std::int64_t> piv(static_cast<size_t>(m));
+            std::vector<double> ud(static_cast<size_t>(m));
+            char err[256] = {0};
+            const ellp_status s = ellp_hip_lu_transposed(static_cast<std::int64_t>(m), static_cast<std::int64_t>(n),
+                                                         std_form.A.a.data(), piv.data(), ud.data(), -1, err, sizeof(err));
+            if (s == ELLP_OPTIMAL) {
+                for (Index i = 0; i < m; ++i) {
+                    if (piv[static_cast<size_t>(i)] != i) lu_p.append_permutation(i, static_cast<Index>(piv[static_cast<size_t>(i)]));
+                    if (std::fabs(ud[static_cast<size_t>(i)]) < EPS) small_diag = true;
+                }
+                done = true;
+            } else if (force && force[0] == '1') {
+                throw std::runtime_error(std::string("device LU failed: ") + err);
+            }
+        }
+        if (!done) {
+            dense::LU lu_t(std_form.A.transpose());
+            small_diag = lu_t.any_small_diag(EPS);
+            lu_p = lu_t.p();
+        }
+    }
+    if (small_diag) throw EllPPanic("should always have a basis available");
     if (n < m) throw EllPPanic("index out of bounds: fewer columns than rows in the box problem");
     std::vector<Index> perm_cols(static_cast<size_t>(n));
     for (Index j = 0; j < n; ++j) perm_cols[static_cast<size_t>(j)] = j;
-    lu_t.p().permute_rows(perm_cols);
+    lu_p.permute_rows(perm_cols);
     std::vector<Basic> B;
     std::vector<Nonbasic> N;
     for (Index i = 0; i < m; ++i) B.push_back({static_cast<size_t>(perm_cols[static_cast<size_t>(i)])});

@@ -356,6 +356,15 @@ void ellp_engine_destroy(ellp_engine *e);
 ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out, double *rdiag_out,
                                    int device, char *errbuf, size_t errbuf_len);
 
+/* LU with partial pivoting of A^T on the device: `std_form.A.transpose().lu()` of DualPhase1::new
+ * (src/solvers/dual/dual_problem.rs:139-160) reduced to what :141-160 consume.  A: m x nv column-major (the box
+ * problem's standard-form matrix), nv >= m.  pivot_out[i] = the row of A^T (= column of A) exchanged with row i at
+ * step i (i itself: no exchange; also for a skipped zero column), udiag_out[i] = U_ii, both of length m.  Every
+ * floating-point result is bitwise what the host loop of ellp_amd/csrc/host/dense.h (LU) produces.
+ * device < 0: current device. */
+ellp_status ellp_hip_lu_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out, double *udiag_out,
+                                   int device, char *errbuf, size_t errbuf_len);
+
 #ifdef __cplusplus
 }
 #endif
