@@ -13,11 +13,14 @@
 //
 // M = A^T (nv x m) is walked through A's own column-major storage: row r of M is column r of A, m contiguous
 // doubles — so a row swap moves two contiguous rows, the trailing update of a row is a contiguous stream, and
-// the matrix needs no transposition.  One launch per elimination step: each wave updates one row (its
-// multiplier from the pivot row parked in a scratch buffer by the previous launch), reports |M[r, i+1]| for
-// the next pivot search, and the block that finishes last folds the per-block candidates (first maximum by
-// row), parks the next pivot row and the row it displaces, and records the pivot — rows are swapped lazily:
-// the displaced row is read from its parked copy by the wave that owns the pivot's old position.
+// the matrix needs no transposition.  Two launches per elimination step: in k_lut_step each wave updates one
+// row (its multiplier from the pivot row parked in a scratch buffer) and reports |M[r, i+1]| for the next pivot
+// search; the one-block k_lut_fold folds the per-block candidates (first maximum by row), parks the next pivot
+// row and the row it displaces, and records the pivot — rows are swapped lazily: the displaced row is read
+// from its parked copy by the wave that owns the pivot's old position.  (Folding in the block that finishes
+// last, one launch per step, was measured first: every block then needs an agent-scope release fence, which on
+// this part writes back its XCD's L2 — the per-XCD L2s are not coherent with each other — and a launch never
+// took less than 110 us however little there was to eliminate.  A kernel boundary does that write-back once.)
 // Right-looking and unblocked: the whole trailing matrix is read and written once per step (about
 // 16·nv·m²/2 bytes in all: 0.3 TB at config 3's shape); a blocked variant would divide that by the panel width.
 #include <hip/hip_runtime.h>
@@ -32,10 +35,10 @@
 namespace {
 
 struct LuState {
-    long long piv;     // pivot row of the step the next launch eliminates
+    long long piv;     // pivot row of the step the next k_lut_step eliminates
     double diag;       // its entry in the pivot column
     int32_t skip;      // diag == 0: the column is skipped (dense.h: `continue`)
-    uint32_t ticket;   // blocks that have finished in the current launch
+    int32_t pad;
 };
 struct LuCand {
     double v;
@@ -44,15 +47,17 @@ struct LuCand {
 
 constexpr int LU_RPB = 4;  // rows (= waves) per block
 
-// Launch `i` (i = -1: nothing to eliminate, only the search of column 0):
+__device__ __forceinline__ bool lu_better(double ov, long long orr, double bv, long long br) {
+    return orr >= 0 && (br < 0 || ov > bv || (ov == bv && orr < br));
+}
+
+// Launch `i` (i = -1: nothing to eliminate, only the candidates of column 0):
 //   block 0            writes the pivot row of step i to position i (the other half of the lazy swap)
 //   block 1 + b, wave w eliminates row r = i + 1 + 4 b + w with the pivot of step i and reports |M[r, i+1]|
-//   the last block     folds the candidates -> pivot of step i+1, parks rows piv and i+1
-__global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t nv, int64_t i, double *prow, double *irow,
-                                                  LuCand *cands, LuState *st, int64_t *pivot_out, double *udiag_out) {
+__global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t nv, int64_t i, const double *prow,
+                                                  const double *irow, LuCand *cands, const LuState *st) {
     __shared__ double s_v[LU_RPB];
     __shared__ long long s_r[LU_RPB];
-    __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long piv = st->piv;
     const bool skip = i < 0 || st->skip != 0;
@@ -75,17 +80,27 @@ __global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t 
                 if (moved)
                     for (int64_t k = lane; k < i; k += 64) dst[k] = src[k];
                 if (lane == 0) dst[i] = l;
-                for (int64_t k = nxt + lane; k < m; k += 64) {
-                    const double f = -prow[k];
-                    double val;
-                    if (f == 0.0) {
-                        val = src[k];
-                        if (moved) dst[k] = val;
-                    } else {
-                        val = __dadd_rn(__dmul_rn(f, l), src[k]);
-                        dst[k] = val;
+                // four 64-entry chunks in flight per wave: the loop is a chain of dependent round trips otherwise
+                for (int64_t k0 = nxt + lane; k0 < m; k0 += 256) {
+                    double pv[4], sv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t k = k0 + 64 * u;
+                        const int64_t kc = k < m ? k : m - 1;
+                        pv[u] = prow[kc];
+                        sv[u] = src[kc];
                     }
-                    if (k == nxt) first = val;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int64_t k = k0 + 64 * u;
+                        if (k < m) {
+                            const double f = -pv[u];
+                            double val = sv[u];
+                            if (f != 0.0) val = __dadd_rn(__dmul_rn(f, l), val);
+                            if (f != 0.0 || moved) dst[k] = val;
+                            if (u == 0 && k == nxt) first = val;
+                        }
+                    }
                 }
             } else if (nxt < m && lane == 0) {
                 first = dst[nxt];
@@ -105,30 +120,31 @@ __global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t 
         s_v[wave] = cv;
         s_r[wave] = cr;
     }
-    __threadfence();  // this thread's part of the rows is in L2 before the block takes its ticket
     __syncthreads();
     if (tid == 0) {
         double bv = s_v[0];
         long long br = s_r[0];
         for (int w = 1; w < LU_RPB; ++w)
-            if (s_r[w] >= 0 && (br < 0 || s_v[w] > bv || (s_v[w] == bv && s_r[w] < br))) {
+            if (lu_better(s_v[w], s_r[w], bv, br)) {
                 bv = s_v[w];
                 br = s_r[w];
             }
         cands[blockIdx.x] = LuCand{bv, br};
-        __threadfence();
-        const uint32_t t = atomicAdd(&st->ticket, 1u);
-        s_last = (t == gridDim.x - 1) ? 1 : 0;
     }
-    __syncthreads();
-    if (!s_last) return;
-    // ---- the block that finished last: everything the other blocks wrote is visible after this fence
-    __threadfence();
+}
+
+// one block of 1024 threads: the pivot of column nxt from the ncand per-block candidates, rows piv and nxt parked
+__global__ __launch_bounds__(1024) void k_lut_fold(const double *M, int64_t m, int64_t nxt, const LuCand *cands,
+                                                   unsigned ncand, double *prow, double *irow, LuState *st,
+                                                   int64_t *pivot_out, double *udiag_out) {
+    __shared__ double s_v[16];
+    __shared__ long long s_r[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double bv = -1.0;
     long long br = -1;
-    for (unsigned b = tid; b < gridDim.x; b += 256) {
+    for (unsigned b = tid; b < ncand; b += 1024) {
         const LuCand c = cands[b];
-        if (c.r >= 0 && (br < 0 || c.v > bv || (c.v == bv && c.r < br))) {
+        if (lu_better(c.v, c.r, bv, br)) {
             bv = c.v;
             br = c.r;
         }
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t 
     for (int o = 32; o > 0; o >>= 1) {
         const double ov = __shfl_xor(bv, o);
         const long long orr = __shfl_xor(br, o);
-        if (orr >= 0 && (br < 0 || ov > bv || (ov == bv && orr < br))) {
+        if (lu_better(ov, orr, bv, br)) {
             bv = ov;
             br = orr;
         }
@@ -149,14 +165,14 @@ __global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t 
     __syncthreads();
     bv = s_v[0];
     br = s_r[0];
-    for (int w = 1; w < LU_RPB; ++w)
-        if (s_r[w] >= 0 && (br < 0 || s_v[w] > bv || (s_v[w] == bv && s_r[w] < br))) {
+    for (int w = 1; w < 16; ++w)
+        if (lu_better(s_v[w], s_r[w], bv, br)) {
             bv = s_v[w];
             br = s_r[w];
         }
     // br >= 0: row nxt itself is always a candidate (nv >= m)
     const double diag = M[br * m + nxt];
-    for (int64_t k = tid; k < m; k += 256) {
+    for (int64_t k = tid; k < m; k += 1024) {
         prow[k] = M[br * m + k];
         irow[k] = M[nxt * m + k];
     }
@@ -164,7 +180,6 @@ __global__ __launch_bounds__(256) void k_lut_step(double *M, int64_t m, int64_t 
         st->piv = br;
         st->diag = diag;
         st->skip = diag == 0.0 ? 1 : 0;
-        st->ticket = 0;
         pivot_out[nxt] = diag == 0.0 ? nxt : br;  // a skipped column appends no transposition (dense.h)
         udiag_out[nxt] = diag;
     }
@@ -224,7 +239,9 @@ extern "C" ellp_status ellp_hip_lu_transposed(int64_t m, int64_t nv, const doubl
     for (int64_t i = -1; i < m; ++i) {
         const int64_t rows = nv - i - 1;
         const unsigned grid = (unsigned)((rows + LU_RPB - 1) / LU_RPB) + 1;
-        hipLaunchKernelGGL(k_lut_step, dim3(grid), dim3(256), 0, stream, dM, m, nv, i, prow, irow, cands, st, piv, udiag);
+        hipLaunchKernelGGL(k_lut_step, dim3(grid), dim3(256), 0, stream, dM, m, nv, i, prow, irow, cands, st);
+        if (i + 1 < m)
+            hipLaunchKernelGGL(k_lut_fold, dim3(1), dim3(1024), 0, stream, dM, m, i + 1, cands, grid, prow, irow, st, piv, udiag);
     }
     LCHK(hipGetLastError());
     LCHK(hipMemcpyAsync(pivot_out, piv, sizeof(int64_t) * (size_t)m, hipMemcpyDeviceToHost, stream));
