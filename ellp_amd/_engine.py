@@ -27,7 +27,8 @@ class Opts(C.Structure):
     _fields_ = [("max_iter", C.c_uint64), ("eps", C.c_double), ("device", C.c_int32),
                 ("refactor_period", C.c_int32), ("btran_mode", C.c_int32),
                 ("poll_interval", C.c_int32), ("profile", C.c_int32), ("use_graph", C.c_int32),
-                ("pipeline", C.c_int32), ("trace_len", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("pipeline", C.c_int32), ("trace_len", C.c_int32), ("partial_segments", C.c_int32),
+                ("reserved", C.c_int32 * 1)]
 
 
 class Stats(C.Structure):

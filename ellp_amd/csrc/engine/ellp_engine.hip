@@ -118,6 +118,11 @@ struct DevState {
     int32_t need_rebuild;  // that residual was too large for a Newton-Schulz step: the host must rebuild
     int32_t pad_nr;
     unsigned long long iters, pivots, flips;
+    // ---- partial pricing (opts.partial_segments > 1): the nonbasic positions [pp_lo, pp_hi) are
+    // priced, a pass that finds no candidate there moves on to the next segment (pp_skip: the rest of that
+    // iteration's kernels do nothing) and pp_P such passes in a row are the optimality test
+    int64_t pp_lo, pp_hi, pp_S;
+    int32_t pp_P, pp_seg, pp_empty, pp_skip;
 #ifdef ELLP_DBG_STAMPS
     long long dbg[3][4][8];  // [kernel][block selector][stamp] wall_clock64 (100 MHz) — dev builds only
 #endif
@@ -246,6 +251,7 @@ struct PriceArgs {
     int cpb;
     int block0;             // first pricing block of this rank
     double eps;
+    int pp_on;              // partial pricing: only positions [st->pp_lo, st->pp_hi) may enter
 };
 
 // 16-byte column load; NT = non-temporal.  When A_N is much larger than the 256 MiB Infinity Cache
@@ -307,6 +313,15 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     const int64_t j0 = (int64_t)gb * a.cpb;
     const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
     if (j0 >= a.nN) return;  // a rank without pricing blocks still launches one block for the flag above
+    int64_t plo = 0, phi = a.nN;
+    if (MODE == 0 && a.pp_on) {  // partial pricing: a block outside the segment has nothing to offer
+        plo = st->pp_lo;
+        phi = st->pp_hi;
+        if (j1 <= plo || j0 >= phi) {
+            if (tid == 0) a.xc.bk(gb) = -INFINITY;
+            return;
+        }
+    }
     double best = (MODE == 0) ? -INFINITY : INFINITY;
     long long bestpos = -1;
     int buf = 0;
@@ -366,6 +381,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
                     else if (!pos && nb == ELLP_NB_LOWER) key = -rj;
                     else if (nb == ELLP_NB_FREE) key = fabs(rj);
                 }
+                if (jj < plo || jj >= phi) key = -INFINITY;  // a column of a boundary block outside the segment
                 a.xc.r(jj) = rj;
                 a.xc.key(jj) = key;
                 best = fmax(best, key);
@@ -461,6 +477,15 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
     const int64_t j0 = (int64_t)gb * a.cpb;
     const int64_t j1 = (j0 + a.cpb < a.nN) ? j0 + a.cpb : a.nN;
     if (j0 >= a.nN) return;  // a rank without pricing blocks still launches one block for the flag above
+    int64_t plo = 0, phi = a.nN;
+    if (MODE == 0 && a.pp_on) {  // partial pricing: a block outside the segment has nothing to offer
+        plo = st->pp_lo;
+        phi = st->pp_hi;
+        if (j1 <= plo || j0 >= phi) {
+            if (tid == 0) a.xc.bk(gb) = -INFINITY;
+            return;
+        }
+    }
     double best = (MODE == 0) ? -INFINITY : INFINITY;  // lanes 0 and 1 own the pair's two columns
     long long bestpos = -1;
     for (int64_t j = j0 + 2 * wave; j < j1; j += 8) {
@@ -511,6 +536,7 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
                     else if (!pos && nb == ELLP_NB_LOWER) key = -rj;
                     else if (nb == ELLP_NB_FREE) key = fabs(rj);
                 }
+                if (jj < plo || jj >= phi) key = -INFINITY;  // a column of a boundary block outside the segment
                 a.xc.r(jj) = rj;
                 a.xc.key(jj) = key;
                 best = fmax(best, key);
@@ -665,6 +691,7 @@ struct Ftran2Args {
     int nblocks, cpb;
     double eps;
     const double *aq_cur;  // column-sharded engines: the entering position is st->sh_q (k_sh_select), its column is here
+    int pp_on;             // partial pricing (DevState::pp_*)
 };
 
 // NT = double2 per lane that hold one row (ceil(ld/128)); NT == 0: rows are streamed instead
@@ -911,10 +938,26 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     if (q < 0) {
         if (blockIdx.x == 0 && tid == 0) {
             st->iters += 1;
-            st->status = (MODE == 0) ? ELLP_OPTIMAL      // primal…:289-292
-                                     : ELLP_INFEASIBLE;  // dual unbounded, dual…:281-284
+            if (MODE == 0 && a.pp_on && st->pp_empty + 1 < st->pp_P) {
+                // partial pricing: nothing in this segment — the next pass prices the next one; only pp_P empty
+                // passes in a row (every segment, no pivot in between) are the reference's `None => Optimal`
+                const int seg = (st->pp_seg + 1) % st->pp_P;
+                const int64_t lo = (int64_t)seg * st->pp_S;
+                st->pp_seg = seg;
+                st->pp_lo = lo;
+                st->pp_hi = lo + st->pp_S < a.nN ? lo + st->pp_S : a.nN;
+                st->pp_empty = st->pp_empty + 1;
+                st->pp_skip = 1;
+            } else {
+                st->status = (MODE == 0) ? ELLP_OPTIMAL      // primal…:289-292
+                                         : ELLP_INFEASIBLE;  // dual unbounded, dual…:281-284
+            }
         }
         return;
+    }
+    if (MODE == 0 && a.pp_on && blockIdx.x == 0 && tid == 0) {
+        st->pp_empty = 0;
+        st->pp_skip = 0;
     }
     const int at_lower = (MODE == 0) ? (a.Nb[q] == ELLP_NB_LOWER ? 1 : 0) : 0;
     const double sgn = at_lower ? -1.0 : 1.0;
@@ -1232,6 +1275,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->status = st->fin - 1;
         return;
     }
+    if (MODE == 0 && st->pp_skip) return;  // partial pricing: this pass found no candidate in its segment (k_ftran2)
     STAMP(2, 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m = a.m;
@@ -1688,7 +1732,7 @@ struct DriftArgs {
     double tol;
 };
 __global__ __launch_bounds__(256) void k_drift_part(DriftArgs a) {
-    if (a.st->status != ST_RUNNING) return;
+    if (a.st->status != ST_RUNNING || a.st->pp_skip) return;
     const int64_t half = a.ld >> 1;
     const int64_t i2 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t k0 = (int64_t)blockIdx.y * a.cols_per_tile;
@@ -1707,7 +1751,7 @@ __global__ __launch_bounds__(256) void k_drift_part(DriftArgs a) {
 __global__ __launch_bounds__(1024) void k_drift_reduce(DriftArgs a) {
     __shared__ double s_r[16], s_s[16];
     DevState *st = a.st;
-    if (st->status != ST_RUNNING) return;
+    if (st->status != ST_RUNNING || st->pp_skip) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double sgn = st->s_at_lower ? -1.0 : 1.0;  // alpha = sgn * d (k_ftran2 stores d = +-alpha)
     const double *aq = a.aq_cur ? a.aq_cur : a.A_N + st->s_q * a.ld;
@@ -2406,6 +2450,8 @@ struct ellp_engine {
     bool small = false;      // run() uses k_small
     bool w_valid = true;     // the explicit inverse W (not kept by k_small) matches A_B
     size_t small_lds = 0;
+    int pp_P = 0;            // partial pricing: number of segments (<= 1: off)
+    int64_t pp_S = 0;        // positions per segment
     char *slab = nullptr;  // see dmalloc
     size_t slab_size = 0, slab_used = 0;
     unsigned long long *small_stamps = nullptr;  // ELLP_SMALL_STAMPS: per-phase tick sums of k_small, printed at destroy
@@ -2594,6 +2640,7 @@ void launch_price(ellp_engine *e) {
     a.cpb = e->cpb;
     a.block0 = e->rank * e->nbs;
     a.eps = e->eps;
+    a.pp_on = e->pp_P > 1 ? 1 : 0;
     int mine = e->nblocks - a.block0;
     if (mine > e->nbs) mine = e->nbs;
     if (mine <= 0) mine = 1;  // empty shard (more ranks than pricing blocks): the block only serves DevState::tiny
@@ -2631,6 +2678,7 @@ void launch_ftran2(ellp_engine *e) {
     a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.cpb = e->cpb; a.eps = e->eps;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr;
+    a.pp_on = (MODE == 0 && e->pp_P > 1) ? 1 : 0;
     const dim3 g(e->ftran_blocks), b(256);
     const int64_t nt = ((e->ld >> 1) + 63) / 64;  // double2 per lane for one row
     if (nt <= 4) hipLaunchKernelGGL((k_ftran2<MODE, 4>), g, b, e->ftran_lds, e->stream, a);
@@ -3528,6 +3576,21 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         init.status = ST_RUNNING;
         init.r = -1;
         init.lr = -1;
+        init.pp_hi = n_N;
+        if (kind == ELLP_ENGINE_PRIMAL && e->opts.partial_segments > 1 && n_N > 0) {
+            // partial pricing (f4): segments of ceil(|N| / P) positions, never more segments than positions
+            int P = e->opts.partial_segments;
+            if ((int64_t)P > n_N) P = (int)n_N;
+            const int64_t S = (n_N + P - 1) / P;
+            P = (int)((n_N + S - 1) / S);
+            if (P > 1) {
+                e->pp_P = P;
+                e->pp_S = S;
+                init.pp_P = P;
+                init.pp_S = S;
+                init.pp_hi = S;
+            }
+        }
         if (kind == ELLP_ENGINE_DUAL) {
             UCHK(hipMemsetAsync(e->y, 0, sizeof(double) * (size_t)ld, e->stream));
             UCHK(hipMemcpyAsync(e->y, y, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, e->stream));
@@ -3578,8 +3641,8 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     {
         const int pl = e->opts.pipeline;
         e->small_lds = small_lds_bytes(m, n_N);
-        const bool wanted = pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
-                                        e->opts.profile == 0);
+        const bool wanted = e->pp_P <= 1 && (pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
+                                                         e->opts.profile == 0));
         if (pl == 3 && e->small_lds == 0) {
             set_err(errbuf, errlen, "pipeline 3 (one persistent workgroup) needs m <= %d and its LU in LDS", SMALL_MAX_M);
             ellp_engine_destroy(e);
@@ -3608,8 +3671,8 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     // two launches per primal iteration from m = 1024 (ellp_lagged.inc), or on request
     {
         const int pl = e->opts.pipeline;
-        e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 &&
-                    (pl == 2 || (pl == 0 && m >= 1024));
+        e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
+                    (pl == 2 || (pl == 0 && m >= 1024));  // partial pricing runs on the three-launch pipeline
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
     }
@@ -4232,6 +4295,11 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     ns.pe_valid = 0;
     ns.open = 0;
     ns.mv_pending = 0;
+    ns.pp_seg = 0;  // partial pricing starts over with the first segment
+    ns.pp_empty = 0;
+    ns.pp_skip = 0;
+    ns.pp_lo = 0;
+    ns.pp_hi = e->pp_P > 1 ? e->pp_S : e->nN;
     ns.need_rebuild = 0;
     ns.panic_code = 0;
     ns.iters = ns.pivots = ns.flips = 0;
@@ -4521,6 +4589,10 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
     }
     if (world * SH_KC > WAVE) {
         set_err(errbuf, errlen, "at most %d ranks", WAVE / SH_KC);
+        return ELLP_ERR_ARG;
+    }
+    if (e->pp_P > 1) {
+        set_err(errbuf, errlen, "partial pricing is implemented for one GPU");
         return ELLP_ERR_ARG;
     }
     if (e->colshard) {

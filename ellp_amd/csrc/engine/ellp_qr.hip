@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void k_qr_reflect(double *xbuf, int64_t len, i
 }
 
 // dot[j] = sum_r x[r] * M[i + r, j], one thread per trailing column j > i, accumulated in the host's
-// order; the loads of 32 consecutive rows are issued together so that the sequential chain of adds
-// is not also a chain of memory round trips.  Writes f2[j] = -2 * dot and clears the column's
+// order; the loads of 32 consecutive rows are issued together, one batch ahead of the additions, so that the
+// sequential chain of adds is not also a chain of memory round trips.  Writes f2[j] = -2 * dot and clears the column's
 // pivot-search candidate for k_qr_update.
 constexpr int DOTB = 32;
 __global__ __launch_bounds__(64) void k_qr_dot(const double *A, int64_t m, int64_t nv, int64_t i, const double *xbuf,
@@ -167,15 +167,35 @@ __global__ __launch_bounds__(64) void k_qr_dot(const double *A, int64_t m, int64
     const double *cj = A + j + i * m;  // M[i + r, j] = cj[r * m]
     double dot = 0.0;
     int64_t r0 = 0;
-    for (; r0 + DOTB <= len; r0 += DOTB) {
-        double v[DOTB], xv[DOTB];
+    // software pipeline: the loads of batch b+1 are issued before the additions of batch b, so a wave always has
+    // 32-64 row loads in flight (the kernel has one wave per 64 columns: few waves, each must keep the memory busy)
+    double v[DOTB], xv[DOTB];
+    if (DOTB <= len) {
 #pragma unroll
         for (int k = 0; k < DOTB; ++k) {
-            v[k] = cj[(r0 + k) * m];
-            xv[k] = xbuf[r0 + k];
+            v[k] = cj[k * m];
+            xv[k] = xbuf[k];
+        }
+    }
+    for (; r0 + DOTB <= len; r0 += DOTB) {
+        double vn[DOTB], xn[DOTB];
+        const bool more = r0 + 2 * DOTB <= len;
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < DOTB; ++k) {
+                vn[k] = cj[(r0 + DOTB + k) * m];
+                xn[k] = xbuf[r0 + DOTB + k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < DOTB; ++k) dot += xv[k] * v[k];
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < DOTB; ++k) {
+                v[k] = vn[k];
+                xv[k] = xn[k];
+            }
+        }
     }
     for (; r0 < len; ++r0) dot += xbuf[r0] * cj[r0 * m];
     f2[j] = -2.0 * dot;

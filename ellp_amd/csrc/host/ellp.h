@@ -181,6 +181,7 @@ struct EngineOptions {
     int refactor_period = 0;
     int btran_mode = 0;
     int poll_interval = 0;
+    int partial_segments = 0;  // ellp_opts.partial_segments (> 1: partial pricing, an opt-in extension)
     int pipeline = 0;  // ellp_opts.pipeline: 0 = chosen by size, 1 / 2 = launches per iteration, 3 = persistent small kernel
 };
 

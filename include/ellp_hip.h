@@ -75,7 +75,13 @@ typedef struct ellp_opts {
     int32_t trace_len;       /* > 0: keep the objective after each of the last `trace_len` iterations in a ring buffer on
                                 the device (ellp_engine_read_trace) — what the reference's `debug!("{iter} | {obj}")` line
                                 (primal…:161, dual…:189) prints; off by default, as the reference's logging is */
-    int32_t reserved[2];
+    int32_t partial_segments; /* > 1: partial pricing (an extension the reference's README lists as future work, not its
+                                 behaviour): the nonbasic positions are cut into this many segments of
+                                 ceil(|N| / segments) positions; an iteration prices one segment with the reference's
+                                 entering rule; a pass that finds no candidate moves to the next segment (and counts
+                                 as an iteration), `segments` such passes in a row are the optimality test.  Primal
+                                 engines on one GPU, three-launch pipeline.  0 or 1: every column every iteration */
+    int32_t reserved[1];
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */

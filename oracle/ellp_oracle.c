@@ -71,6 +71,14 @@ void eo_set_dense_lu(int on) { g_dense_lu = on; }
  * processed by one thread in the sequential order, so every number is bit for bit the one-thread
  * result.  1 (the default) everywhere else — in particular for the timed CPU baseline of bench.py, which
  * is the reference's single-threaded algorithm. */
+/* Partial pricing (NOT the reference's behaviour: an extension its README lists as future work),
+ * restated here so that the engine's opt-in implementation (ellp_opts.partial_segments) has a checker: the nonbasic
+ * positions are cut into P segments of S = ceil(|N| / P) positions; a loop body prices the current segment with the
+ * reference's entering rule; a body that finds no candidate moves to the next segment, and P such bodies in a row
+ * are the optimality test.  P <= 1: off.  Used by eo_primal_solve_with_initial only. */
+static int g_partial_segments = 0;
+void eo_set_partial_segments(int P) { g_partial_segments = P > 1 ? P : 0; }
+
 static int g_setup_threads = 1;
 void eo_set_setup_threads(int n) { g_setup_threads = n > 1 ? n : 1; }
 
@@ -1067,6 +1075,17 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
     int status = EO_ERR_PANIC;
     uint64_t iter = 1;
     uint64_t entered = 0;
+    /* partial pricing (see g_partial_segments): the same normalisation of P and S as the engine's */
+    int pp_P = 0, pp_seg = 0, pp_empty = 0;
+    int64_t pp_S = nN;
+    if (g_partial_segments > 1 && nN > 0) {
+        int P = g_partial_segments;
+        if ((int64_t)P > nN) P = (int)nN;
+        pp_S = (nN + P - 1) / P;
+        P = (int)((nN + pp_S - 1) / pp_S);
+        if (P > 1) pp_P = P;
+        else pp_S = nN;
+    }
     for (;;) {
         if (iter > max_iter) { /* :163-166 */
             status = EO_MAXITER;
@@ -1104,7 +1123,9 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
         double r1 = 0.0;
         int64_t q = -1;
         int nan_seen = 0;
-        for (int64_t j = 0; j < nN; ++j) {
+        const int64_t pp_lo = pp_P > 1 ? (int64_t)pp_seg * pp_S : 0;
+        const int64_t pp_hi = pp_P > 1 ? (pp_lo + pp_S < nN ? pp_lo + pp_S : nN) : nN;
+        for (int64_t j = pp_lo; j < pp_hi; ++j) {
             double rj = r[j];
             if (fabs(rj) < EPS) continue;
             double key;
@@ -1139,9 +1160,15 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
             break;
         }
         if (!have) { /* :289-292 */
+            if (pp_P > 1 && pp_empty + 1 < pp_P) { /* nothing in this segment: on to the next one */
+                pp_seg = (pp_seg + 1) % pp_P;
+                pp_empty += 1;
+                continue;
+            }
             status = EO_OPTIMAL;
             break;
         }
+        pp_empty = 0;
         const int64_t jq = N[q];
         /* :295-300 FTRAN */
         memcpy(d, A + jq * m, sizeof(double) * (size_t)m);

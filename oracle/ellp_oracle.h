@@ -157,6 +157,8 @@ void eo_set_trace(eo_trace_fn fn, void *user);
 void eo_set_dense_lu(int on);
 /* threads for the once-per-solve setup factorizations (bitwise the one-thread results); default 1 */
 void eo_set_setup_threads(int n);
+/* partial pricing for eo_primal_solve_with_initial (an extension, see ellp_oracle.c); P <= 1: off */
+void eo_set_partial_segments(int P);
 
 typedef struct eo_result {
     int status;       /* EO_OPTIMAL.. or error */

@@ -110,6 +110,7 @@ def lib():
     L.eo_result_free.argtypes = [C.POINTER(_Result)]
     L.eo_set_dense_lu.argtypes = [C.c_int]
     L.eo_set_setup_threads.argtypes = [C.c_int]
+    L.eo_set_partial_segments.argtypes = [C.c_int]
     L.eo_synth_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
     _lib = L
@@ -384,6 +385,11 @@ def synth_dense_lp(seed, m, n):
     c = np.zeros(n)
     lib().eo_synth_dense_lp(int(seed), m, n, _ptr(A), _ptr(b), _ptr(c))
     return A, b, c
+
+
+def set_partial_segments(P):
+    """partial pricing in primal_solve_with_initial (an extension, see ellp_oracle.c); P <= 1 turns it off"""
+    lib().eo_set_partial_segments(int(P))
 
 
 def synth_problem(seed, m, n):
