@@ -15,7 +15,8 @@ set) it is one of the ranks.  N ranks cooperate on ONE pivot stream: the nonbasi
 and pricing) are sharded, everything else is replicated ("scaling": "strong").
 
 Besides the headline workload (config 3, so that N=1 is comparable from round to round) every line
-carries a `config5` object: BASELINE.json's config 5 (m=4000, n=40000, primal), the one it names
+carries a `config4` object (BASELINE.json's config 4: the same LP shape through the dual loop, N = 1 only) and
+a `config5` object: BASELINE.json's config 5 (m=4000, n=40000, primal), the one it names
 for 1/2/4/8 GPUs, run the same way — pivots/s, the pricing kernel's rate per GPU and its fraction
 of the HBM roofline.
 """
@@ -59,6 +60,10 @@ def parse():
                     help="1/0: also run config 5 (m=4000 n=40000) and report it as `config5` (-1: yes when the "
                          "headline workload is config 3)")
     ap.add_argument("--config5-steps", type=int, default=1000)
+    ap.add_argument("--config4", type=int, default=-1,
+                    help="1/0: also run config 4 (m=2000 n=5000, dual simplex) on one GPU and report it as `config4` "
+                         "(-1: yes when the headline is config 3 and N = 1)")
+    ap.add_argument("--config4-steps", type=int, default=2000)
     ap.add_argument("--long-window", type=int, default=3000,
                     help="when --steps < 1000: additionally time a window of this many steps (0 off)")
     return ap.parse_args()
@@ -373,6 +378,17 @@ def main():
                   "achieved_GBps_algorithmic": round(c5_bytes * c5m["steps"] / c5m["dt"] / 1e9, 1),
                   "sharded_check": c5m.get("sharded_check")}
         del c5m
+    c4 = None
+    if (args.config4 == 1 or (args.config4 < 0 and is_c3)) and world == 1:
+        c4m = measure(ctx, args, 2000, 5000, args.seed, "dual", args.config4_steps, 200, min(args.profile_steps, 100))
+        r4 = roofline_of(c4m, 2000, 5000, "dual", 1)
+        c4 = {"workload": f"random dense covering LP m=2000 n=5000 (seed {args.seed}), dual simplex from the slack basis, "
+                          f"std-form 2000x{c4m['n_cols']} with |N|={c4m['nN']}",
+              "value": round(c4m["steps"] / c4m["dt"], 2), "unit": "pivots/s", "steps": c4m["steps"],
+              "ms_per_step": round(1e3 * c4m["dt"] / c4m["steps"], 6), "roofline": r4,
+              "kernels_us": {k: round(v["avg_us"], 3) for k, v in c4m["prof"].items()},
+              "achieved_GBps_algorithmic": round(c4m["alg_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1)}
+        del c4m
     if ctx.dist is not None:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
@@ -453,6 +469,8 @@ def main():
         lw = head["long_window"]
         lw["vs_value"] = round(lw["value"] / pivots_per_s, 4)
         out["long_window"] = lw
+    if c4 is not None:
+        out["config4"] = c4
     if c5 is not None:
         out["config5"] = c5
     if cpu:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/netlib_orders.py [orders_per_problem] [seed] [pipeline] — the campaign behind
+"""tests/campaign/netlib_orders.py [orders_per_problem] [seed] [pipeline] — the campaign behind
 tests/test_gpu_random.py::test_netlib_in_random_orders, without stopping at the first failure: netlib
 AFIRO / ADLITTLE / BLEND in random variable and constraint orders through the dual and primal loops,
 oracle (CPU) against engine (GPU).  Every order on which the two end differently (status or objective)
@@ -12,7 +12,7 @@ import zlib
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/trace_order.py FAILURES.json INDEX [PHASE] — step a failing netlib order of
-tools/netlib_orders.py through the dual loop one iteration at a time, oracle (CPU) beside engine
+"""tests/campaign/trace_order.py FAILURES.json INDEX [PHASE] — step a failing netlib order of
+tests/campaign/netlib_orders.py through the dual loop one iteration at a time, oracle (CPU) beside engine
 (GPU), and print where they part and what B^-1 looks like there."""
 import json
 import os
@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import GOLDEN, known_answers, read_mps  # noqa: E402

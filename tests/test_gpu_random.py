@@ -391,7 +391,7 @@ def _regression_orders():
 @pytest.mark.parametrize("case", _regression_orders(), ids=lambda c: f"{c['name']}-{c['tag']}")
 def test_netlib_regression_orders(case):
     """Variable/constraint orders of the netlib LPs on which an earlier engine ended wrongly
-    (tests/golden/netlib_orders.json: the permutations themselves, found by tools/netlib_orders.py);
+    (tests/golden/netlib_orders.json: the permutations themselves, found by tests/campaign/netlib_orders.py);
     each must now end at the pinned optimum through both loops."""
     import os
     from helpers import GOLDEN, known_answers, read_mps
