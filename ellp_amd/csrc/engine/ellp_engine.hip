@@ -2358,6 +2358,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
 
 #include "ellp_gemm.inc"
 #include "ellp_lagged.inc"
+#include "ellp_dualfu.inc"
 #include "ellp_shard.inc"
 #include "ellp_rebuild.inc"
 #include "ellp_small.inc"
@@ -2411,6 +2412,7 @@ struct ellp_engine {
     uint64_t rebuild_shortcuts = 0;
     double *aq_save = nullptr, *bmin = nullptr;  // two-launch pipeline: parked entering column, row-block minima of lambda
     bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
+    bool dual_fused = false;  // dual: FTRAN and eta update in one pass over B^-1 (ellp_dualfu.inc)
     bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
     size_t price2_lds = 0;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
@@ -3093,10 +3095,43 @@ void launch_primal_iteration(ellp_engine *e) {
     e->enqueued += 1;
 }
 
+// FTRAN + eta update + x_B / d_N / y updates in one pass, then the closing block (ellp_dualfu.inc)
+void launch_dual_fu(ellp_engine *e) {
+    {
+        Prof p(e, ELLP_K_FTRAN);
+        DualFuArgs a{};
+        a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
+        a.N_index = e->N_index; a.B_index = e->B_index; a.x = e->x; a.d = e->d; a.y = e->y; a.dd = e->dd;
+        a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.eps = e->eps;
+        const dim3 g((unsigned)((e->m + UPD_ROWS - 1) / UPD_ROWS) + DFU_BOOK), b(256);
+        const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
+        if (nr <= 1) hipLaunchKernelGGL((k_dual_fu<1>), g, b, 0, e->stream, a);
+        else if (nr <= 2) hipLaunchKernelGGL((k_dual_fu<2>), g, b, 0, e->stream, a);
+        else if (nr <= 4) hipLaunchKernelGGL((k_dual_fu<4>), g, b, 0, e->stream, a);
+        else hipLaunchKernelGGL((k_dual_fu<8>), g, b, 0, e->stream, a);
+    }
+    {
+        Prof p(e, ELLP_K_DUPDATE);
+        DualCloseArgs c{e->d, e->A_N, e->A_B, e->c_B, e->c_N, e->x, e->dd, e->lb, e->ub, e->kindv, e->B_index, e->N_index,
+                        e->Nb, e->st, e->m, e->ld, e->ill_tol, e->eps, Trace{e->trace_obj, e->trace_it, e->trace_len}};
+        hipLaunchKernelGGL(k_dual_close, dim3(1), dim3(256), 0, e->stream, c);
+    }
+}
+
 void launch_dual_iteration(ellp_engine *e) {
     {
         Prof p(e, ELLP_K_DPRICE);
         launch_price<1>(e);
+    }
+    // the drift monitor compares A_B alpha_q with a_q between FTRAN and the update: those iterations keep the
+    // three-launch form (both forms leave the same state behind)
+    const bool drift_now = e->drift_every > 0 && e->since_drift + 1 >= (uint64_t)e->drift_every;
+    if (e->dual_fused && !drift_now) {
+        if (e->drift_every > 0) e->since_drift += 1;
+        launch_dual_fu(e);
+        e->since_refactor += 1;
+        e->enqueued += 1;
+        return;
     }
     {
         Prof p(e, ELLP_K_FTRAN);
@@ -3673,6 +3708,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         const int pl = e->opts.pipeline;
         e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
                     (pl == 2 || (pl == 0 && m >= 1024));  // partial pricing runs on the three-launch pipeline
+        e->dual_fused = !e->small && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 1024));
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
     }
@@ -4012,7 +4048,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                 dst[16] = (double)e->refactors;
                 dst[17] = (double)e->resyncs;
                 dst[18] = h.resid;
-                dst[19] = e->small ? 0.0 : (e->lagged ? 2.0 : 3.0);  // 0: whole iterations inside one persistent launch
+                dst[19] = e->small ? 0.0 : ((e->lagged || e->dual_fused) ? 2.0 : 3.0);  // 0: whole iterations inside one persistent launch
                 if (cap >= 22) {
                     dst[20] = (double)e->rebuild_shortcuts;
                     dst[21] = e->t_setup;

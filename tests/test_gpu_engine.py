@@ -437,3 +437,46 @@ def test_two_launch_pipeline_takes_the_same_pivots(m, n):
     assert st3 == E.OPTIMAL and tr3[-1][0] == tr1[-1][0]
     np.testing.assert_array_equal(tr3[-1][1], tr1[-1][1])
     assert abs(fp3.obj()) < 1e-9
+
+
+@pytest.mark.parametrize("m,n", [(260, 700), (600, 1500)])
+def test_fused_dual_iteration_takes_the_same_pivots(m, n):
+    """ellp_opts.pipeline = 2 on a dual engine (FTRAN and eta update in one pass over B^-1, a closing block for
+    the swap and the next leaving row; ellp_dualfu.inc) against pipeline = 1 (three launches): the same
+    arithmetic except for the summation order of the FTRAN dot products, so on these well-conditioned LPs the same
+    pivots, slice for slice, the same duals and the same optimum; drift-monitor iterations (three-launch form
+    inside the fused loop) and slices of every length included."""
+    E = _engine()
+    from ellp_amd import synth
+    f = synth.dual_start_flat(20260301, m, n)
+
+    def solve(pipeline, slices, **kw):
+        fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"],
+                           f["x"], f["B"], f["N"], f["Nb"], f["y"], f["d"])
+        eng = E.Engine(E.ENGINE_DUAL, fp, E.default_opts(max_iter=None, pipeline=pipeline, **kw))
+        assert eng.counters()["launches_per_iteration"] == (3 if pipeline == 1 else 2)
+        trace = []
+        st = E.MAXITER
+        k = 0
+        while st == E.MAXITER:
+            st, stats, msg = eng.run(slices[k % len(slices)])
+            k += 1
+            eng.read_point()
+            trace.append((int(stats.iters), fp.B.copy()))
+            assert k < 200000
+        eng.close()
+        return st, trace, fp
+    st1, tr1, fp1 = solve(1, [41])
+    st2, tr2, fp2 = solve(2, [41])
+    assert st1 == st2 == E.OPTIMAL
+    assert len(tr1) == len(tr2)
+    for (i1, B1), (i2, B2) in zip(tr1, tr2):
+        assert i1 == i2
+        np.testing.assert_array_equal(B1, B2)
+    sc = 1 + np.abs(fp1.x).max()
+    np.testing.assert_allclose(fp1.x, fp2.x, rtol=0, atol=1e-9 * sc)
+    np.testing.assert_allclose(fp1.y, fp2.y, rtol=0, atol=1e-9 * (1 + np.abs(fp1.y).max()))
+    np.testing.assert_allclose(fp1.d, fp2.d, rtol=0, atol=1e-9 * (1 + np.abs(fp1.d).max()))
+    st3, tr3, fp3 = solve(2, [1, 2, 3, 5], refactor_period=200)   # a period > 64 switches the drift monitor on
+    assert st3 == E.OPTIMAL and tr3[-1][0] == tr1[-1][0]
+    np.testing.assert_array_equal(tr3[-1][1], tr1[-1][1])
