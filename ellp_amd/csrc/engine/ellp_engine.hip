@@ -3102,6 +3102,7 @@ void launch_dual_fu(ellp_engine *e) {
         DualFuArgs a{};
         a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
         a.N_index = e->N_index; a.B_index = e->B_index; a.x = e->x; a.d = e->d; a.y = e->y; a.dd = e->dd;
+        a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.lrow = e->binfo; a.ldelta = e->bmin; a.lside = e->bmin + e->m;
         a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.eps = e->eps;
         const dim3 g((unsigned)((e->m + UPD_ROWS - 1) / UPD_ROWS) + DFU_BOOK), b(256);
         const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
@@ -3113,7 +3114,8 @@ void launch_dual_fu(ellp_engine *e) {
     {
         Prof p(e, ELLP_K_DUPDATE);
         DualCloseArgs c{e->d, e->A_N, e->A_B, e->c_B, e->c_N, e->x, e->dd, e->lb, e->ub, e->kindv, e->B_index, e->N_index,
-                        e->Nb, e->st, e->m, e->ld, e->ill_tol, e->eps, Trace{e->trace_obj, e->trace_it, e->trace_len}};
+                        e->Nb, e->binfo, e->bmin, e->bmin + e->m, (int)((e->m + UPD_ROWS - 1) / UPD_ROWS), e->st, e->m, e->ld,
+                        e->ill_tol, e->eps, Trace{e->trace_obj, e->trace_it, e->trace_len}};
         hipLaunchKernelGGL(k_dual_close, dim3(1), dim3(256), 0, e->stream, c);
     }
 }
