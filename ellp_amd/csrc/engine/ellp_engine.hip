@@ -2411,6 +2411,8 @@ struct ellp_engine {
     int bl_splits = 1;
     uint64_t rebuild_shortcuts = 0;
     double *aq_save = nullptr, *bmin = nullptr;  // two-launch pipeline: parked entering column, row-block minima of lambda
+    bool hst_fresh = false;  // h_st is the device state as the previous call (an ellp_engine_run) left it: no read-back needed
+    bool obj_fresh = false;  // h_st->obj is c . x of the state in h_st (primal; see ellp_engine_run / fill_stats)
     bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
     bool dual_fused = false;  // dual: FTRAN and eta update in one pass over B^-1 (ellp_dualfu.inc)
     bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
@@ -3200,7 +3202,9 @@ void fill_stats(ellp_engine *e, ellp_stats *stats) {
     stats->bound_flips = e->h_st->flips;
     stats->refactors = e->refactors + e->refreshes;
     stats->obj = e->h_st->obj;
-    if (e->kind == ELLP_ENGINE_PRIMAL && e->st) {
+    if (e->obj_fresh) {
+        e->obj_fresh = false;  // ellp_engine_run computed c . x in front of the read-back this state came from
+    } else if (e->kind == ELLP_ENGINE_PRIMAL && e->st) {
         hipLaunchKernelGGL(k_primal_obj, dim3(1), dim3(1024), 0, e->stream, e->c_B, e->c_N, e->x, e->B_index,
                            e->N_index, e->m, e->nN, e->st);
         double v = 0.0;
@@ -3835,6 +3839,7 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
 }
 
 double ellp_engine_refresh(ellp_engine *e) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return NAN;
     if (hipSetDevice(e->device) != hipSuccess) return NAN;
     if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return NAN;
@@ -3856,6 +3861,7 @@ double ellp_engine_refresh(ellp_engine *e) {
 }
 
 ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     e->w_valid = true;  // about to be
@@ -3896,9 +3902,12 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             launch_dleave(e);
             e->need_dleave = false;
         }
-        // a previous slice may already have terminated
-        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        // a previous slice may already have terminated (h_st is current if the previous call was a run that read it)
+        if (!e->hst_fresh) {
+            HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+        }
+        e->hst_fresh = false;
         reconcile_counters(e);
         adopt_fin(e);
         if (e->h_st->status != ST_RUNNING) {
@@ -3921,7 +3930,8 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 const uint64_t lpoll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : 64;
                 bool pending[2] = {false, false};
                 bool stop = false;
-                int slot = 0;
+                int slot = 0, last_slot = -1, waited_slot = -1;
+                bool last_is_final = false;
                 uint64_t to_launch = remaining;
                 while (!stop) {
                     if (to_launch > 0) {
@@ -3932,22 +3942,37 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                             else launch_dual_iteration(e);
                         }
                         to_launch -= batch;
+                        if (to_launch == 0 && e->kind == ELLP_ENGINE_PRIMAL) {
+                            // the objective ellp_stats reports (c . x) rides on the last read-back instead of costing a
+                            // launch and a synchronisation of its own after the loop (fill_stats)
+                            hipLaunchKernelGGL(k_primal_obj, dim3(1), dim3(1024), 0, e->stream, e->c_B, e->c_N, e->x, e->B_index,
+                                               e->N_index, e->m, e->nN, e->st);
+                        }
                         HIPCHK(hipMemcpyAsync(&e->h_look[slot], e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
                         HIPCHK(hipEventRecord(e->look_ev[slot], e->stream));
                         pending[slot] = true;
+                        last_slot = slot;
+                        last_is_final = to_launch == 0;
                     }
                     const int other = slot ^ 1;
                     const int wait_on = pending[other] ? other : (to_launch == 0 && pending[slot] ? slot : -1);
                     if (wait_on >= 0) {
                         HIPCHK(hipEventSynchronize(e->look_ev[wait_on]));
                         pending[wait_on] = false;
+                        waited_slot = wait_on;
                         if (e->h_look[wait_on].status != ST_RUNNING || e->h_look[wait_on].tiny || e->h_look[wait_on].fin) stop = true;
                     }
                     if (to_launch == 0 && !pending[0] && !pending[1]) break;
                     slot ^= 1;
                 }
-                HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
-                HIPCHK(hipStreamSynchronize(e->stream));
+                if (last_is_final && waited_slot == last_slot && !pending[0] && !pending[1]) {
+                    // the read-back just waited for came behind everything that was enqueued: it IS the final state
+                    *e->h_st = e->h_look[last_slot];
+                    e->obj_fresh = e->kind == ELLP_ENGINE_PRIMAL;
+                } else {
+                    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+                    HIPCHK(hipStreamSynchronize(e->stream));
+                }
                 HIPCHK(hipGetLastError());
                 reconcile_counters(e);
                 adopt_fin(e);
@@ -3986,11 +4011,18 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         fill_stats(e, stats);
         stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    // A slice that ends normally has read h_st behind its last iteration; what may have been enqueued after that
+    // read (fill_stats' objective kernel, a follow-up refresh) changes neither the status nor the iteration
+    // counter, and a request it raises is seen by the next slice's first read-back.  So the next ellp_engine_run
+    // need not start with a read-back of its own (15 us of a 20-iteration slice).
+    e->hst_fresh = result == ELLP_MAXITER && !e->small && e->world == 1 && !e->colshard && e->nN > 0 &&
+                   e->h_st->status == ST_RUNNING;
     return result;
 }
 
 ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, int64_t *N_index, uint8_t *N_bound,
                                    double *y, double *d, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     launch_flush(e);  // two-launch pipeline: fold and book the iteration that is still open
@@ -4007,6 +4039,7 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, 
 }
 
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !dst) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
     if (what != ELLP_TAP_STATE) launch_flush(e);
@@ -4088,6 +4121,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
 }
 
 int64_t ellp_engine_read_trace(ellp_engine *e, uint64_t *iters_out, double *obj_out, int64_t cap) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !iters_out || !obj_out || cap < 0) return ELLP_ERR_ARG;
     if (e->trace_len <= 0) return 0;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
@@ -4115,6 +4149,7 @@ int64_t ellp_engine_read_trace(ellp_engine *e, uint64_t *iters_out, double *obj_
 }
 
 ellp_status ellp_engine_request_maintenance(ellp_engine *e) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
     if (e->small) return ELLP_OPTIMAL;  // k_small carries no inverse: every iteration starts from a fresh LU
@@ -4126,6 +4161,7 @@ ellp_status ellp_engine_request_maintenance(ellp_engine *e) {
 }
 
 ellp_status ellp_engine_debug_scale_inverse(ellp_engine *e, double factor) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
     if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return ELLP_ERR_DEVICE;
@@ -4136,6 +4172,7 @@ ellp_status ellp_engine_debug_scale_inverse(ellp_engine *e, double factor) {
 }
 
 double ellp_engine_inverse_residual(ellp_engine *e) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return NAN;
     if (hipSetDevice(e->device) != hipSuccess) return NAN;
     if (ensure_inverse(e, nullptr, 0) != ELLP_OPTIMAL) return NAN;
@@ -4152,6 +4189,7 @@ double ellp_engine_inverse_residual(ellp_engine *e) {
 
 ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exchange_buffer, char *errbuf,
                                   size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || world < 1 || rank < 0 || rank >= world) {
         set_err(errbuf, errlen, "bad rank/world");
         return ELLP_ERR_ARG;
@@ -4181,12 +4219,14 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
 }
 
 int64_t ellp_engine_segment_doubles(ellp_engine *e, int world) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || world < 1) return ELLP_ERR_ARG;
     const int64_t nbs = (e->nblocks + world - 1) / world;
     return 2 * nbs + 2 * nbs * e->cpb;
 }
 
 ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_doubles, int *rank, int *world) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     if (base) *base = e->X;
     if (seg_doubles) *seg_doubles = e->seg;
@@ -4196,6 +4236,7 @@ ellp_status ellp_engine_exchange_info(ellp_engine *e, void **base, int64_t *seg_
 }
 
 ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     if (hipSetDevice(e->device) != hipSuccess) return ELLP_ERR_DEVICE;
     (void)hipStreamSynchronize(e->stream);
@@ -4204,6 +4245,7 @@ ellp_status ellp_engine_set_stream(ellp_engine *e, void *hip_stream) {
 }
 
 ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     if (phase == 2) {  // second half of this iteration + first half of the next, one host call
         const ellp_status s1 = ellp_engine_step(e, 1, errbuf, errlen);
@@ -4274,6 +4316,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
 }
 
 ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
@@ -4288,6 +4331,7 @@ ellp_status ellp_engine_poll(ellp_engine *e, ellp_stats *stats, char *errbuf, si
 
 ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *bound_kind, const double *lb,
                                 const double *ub, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !c || !bound_kind || !lb || !ub) return ELLP_ERR_ARG;
     if (errbuf && errlen) errbuf[0] = 0;
     if (e->kind != ELLP_ENGINE_PRIMAL) {
@@ -4391,6 +4435,7 @@ static ellp_status dual_point_from_inverse(ellp_engine *e, const double *c_dev, 
 
 ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const double *b, const uint8_t *bound_kind,
                                      const double *lb, const double *ub, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !c || !b || !bound_kind || !lb || !ub) return ELLP_ERR_ARG;
     if (errbuf && errlen) errbuf[0] = 0;
     if (e->kind != ELLP_ENGINE_DUAL || e->small || e->colshard || e->world != 1) {
@@ -4589,6 +4634,7 @@ ellp_status ellp_comm_unique_id(const char *rccl_path, void *id_out, char *errbu
 
 ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const void *id, int rank, int world,
                                   char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !id || world < 1 || rank < 0 || rank >= world) return ELLP_ERR_ARG;
     const RcclApi *api = load_rccl(rccl_path, errbuf, errlen);
     if (!api) return ELLP_ERR_DEVICE;
@@ -4619,6 +4665,7 @@ ellp_status ellp_engine_comm_init(ellp_engine *e, const char *rccl_path, const v
 
 // ---- column-sharded storage: setup, transports, loop (kernels: ellp_shard.inc) ---------------------
 ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || world < 1 || rank < 0 || rank >= world) return ELLP_ERR_ARG;
     if (errbuf && errlen) errbuf[0] = 0;
     if (e->kind != ELLP_ENGINE_PRIMAL) {
@@ -4666,6 +4713,7 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
 }
 
 ellp_status ellp_engine_set_exchange_callback(ellp_engine *e, ellp_exchange_fn fn, void *user) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     e->xfn = fn;
     e->xuser = user;
@@ -4683,6 +4731,7 @@ int ellp_shard_select_compact(const double *packs, int world, int64_t ld, double
 int64_t ellp_shard_pack_doubles(int64_t ld) { return pack_doubles(ld); }
 
 ellp_status ellp_engine_shard_info(ellp_engine *e, double *out6) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !out6) return ELLP_ERR_ARG;
     out6[0] = (double)e->full_exchanges;
     out6[1] = (double)e->column_requests;
@@ -4694,6 +4743,7 @@ ellp_status ellp_engine_shard_info(ellp_engine *e, double *out6) {
 }
 
 ellp_status ellp_engine_mailbox_export(ellp_engine *e, void *handles_out, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !handles_out || !e->colshard) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     static_assert(sizeof(hipIpcMemHandle_t) == ELLP_IPC_HANDLE_BYTES, "IPC handle size");
@@ -4716,6 +4766,7 @@ ellp_status ellp_engine_mailbox_export(ellp_engine *e, void *handles_out, char *
 }
 
 ellp_status ellp_engine_mailbox_connect(ellp_engine *e, const void *all_handles, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || !all_handles || !e->mbox) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     std::vector<double *> slots((size_t)e->world);
@@ -4846,6 +4897,7 @@ ellp_status launch_sharded_iteration(ellp_engine *e, char *errbuf, size_t errlen
 }  // namespace
 
 ellp_status ellp_engine_mailbox_selftest(ellp_engine *e, int rounds, char *errbuf, size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e || e->transport != 2) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
     const int64_t n = pack_doubles(e->ld);
@@ -4948,6 +5000,7 @@ static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats
 
 ellp_status ellp_engine_run_sharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf,
                                     size_t errlen) {
+    if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     if (e->colshard) {
         if (errbuf && errlen) errbuf[0] = 0;
