@@ -3882,6 +3882,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     if (!e) return ELLP_ERR_ARG;
     if (errbuf && errlen) errbuf[0] = 0;
     HIPCHK(hipSetDevice(e->device));
+    e->obj_fresh = false;
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t poll = e->opts.poll_interval > 0 ? (uint64_t)e->opts.poll_interval : (e->m <= 256 ? 64 : 16);
     int64_t period = e->refactor_period;
