@@ -69,9 +69,11 @@ typedef struct ellp_opts {
     int32_t profile;         /* != 0: bracket every launch with HIP events (ellp_stats.kernel_ms) */
     int32_t use_graph;       /* reserved, must be 0 (hipGraph replay of the launch sequence is not implemented:
                                 on gfx950 the per-iteration cost is GPU-side dispatch, not host launches) */
-    int32_t pipeline;        /* launches per primal iteration: 0 = engine default, 1 = three (pricing | FTRAN |
-                                eta update), 2 = two (pricing | eta update of the previous pivot fused with this
-                                iteration's FTRAN: one pass over B^-1 instead of two) */
+    int32_t pipeline;        /* launch structure of an iteration: 0 = engine default by size (m <= 128: 3; m >= 1024: 2;
+                                otherwise 1), 1 = three launches (pricing | FTRAN | eta update), 2 = two bandwidth
+                                passes (primal: pricing | eta update of the previous pivot fused with this iteration's
+                                FTRAN; dual: pricing | FTRAN fused with this iteration's eta update, + a closing block),
+                                3 = the whole loop in one persistent workgroup with an LU per iteration (m <= 128) */
     int32_t trace_len;       /* > 0: keep the objective after each of the last `trace_len` iterations in a ring buffer on
                                 the device (ellp_engine_read_trace) — what the reference's `debug!("{iter} | {obj}")` line
                                 (primal…:161, dual…:189) prints; off by default, as the reference's logging is */
