@@ -3713,8 +3713,8 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     {
         const int pl = e->opts.pipeline;
         e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
-                    (pl == 2 || (pl == 0 && m >= 1024));  // partial pricing runs on the three-launch pipeline
-        e->dual_fused = !e->small && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 1024));
+                    (pl == 2 || (pl == 0 && m >= 384));  // partial pricing runs on the three-launch pipeline; tools/pipeline_threshold.py for the size
+        e->dual_fused = !e->small && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 384));
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
     }

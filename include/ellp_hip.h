@@ -69,7 +69,7 @@ typedef struct ellp_opts {
     int32_t profile;         /* != 0: bracket every launch with HIP events (ellp_stats.kernel_ms) */
     int32_t use_graph;       /* reserved, must be 0 (hipGraph replay of the launch sequence is not implemented:
                                 on gfx950 the per-iteration cost is GPU-side dispatch, not host launches) */
-    int32_t pipeline;        /* launch structure of an iteration: 0 = engine default by size (m <= 128: 3; m >= 1024: 2;
+    int32_t pipeline;        /* launch structure of an iteration: 0 = engine default by size (m <= 128: 3; m >= 384: 2;
                                 otherwise 1), 1 = three launches (pricing | FTRAN | eta update), 2 = two bandwidth
                                 passes (primal: pricing | eta update of the previous pivot fused with this iteration's
                                 FTRAN; dual: pricing | FTRAN fused with this iteration's eta update, + a closing block),
