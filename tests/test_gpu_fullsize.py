@@ -292,3 +292,31 @@ def test_c4_reference_dual_phase1_long_window_parity(dual_phase1_c3):
     np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-8 * (1 + np.abs(ov.x).max()))
     np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-8 * (1 + np.abs(ov.d).max()))
     np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-8 * (1 + np.abs(ov.y).max()))
+
+
+def test_c4_dual_phase1_built_on_the_device_at_full_size(dual_phase1_c3):
+    """SURVEY.md §8 f2 at config 3's size: the LU of A^T that picks the basis (ellp_hip_lu_transposed) gives the
+    oracle's B and N exactly (bitwise the same pivots), and the point made from the resident B^-1
+    (ellp_engine_create_dual_phase1: y, d, labels by the sign of d, x_B) is the oracle's to rounding."""
+    from ellp_amd import _engine as E
+    v = dual_phase1_c3
+    A = np.asarray(v.A).reshape(v.n, v.m).T                    # m x n, column j = variable j
+    piv, ud = E.lu_transposed(A)
+    perm = np.arange(v.n)
+    for i, p in enumerate(piv):                                 # PermutationSequence::permute_rows
+        perm[i], perm[p] = perm[p], perm[i]
+    np.testing.assert_array_equal(perm[:v.m], v.B)
+    np.testing.assert_array_equal(perm[v.m:], v.N[:v.nN])
+    assert np.abs(ud).min() >= 1e-10
+    eng = E.Engine.dual_phase1(v.m, v.n, v.A, v.c, v.b, v.kind, v.lb, v.ub, perm[:v.m], perm[v.m:], E.default_opts(max_iter=None))
+    eng.read_point()
+    fp = eng.fp
+    eng.close()
+    sc = 1 + max(np.abs(v.x).max(), np.abs(v.y).max(), np.abs(v.d).max())
+    np.testing.assert_allclose(fp.y, v.y, rtol=0, atol=1e-9 * sc)
+    np.testing.assert_allclose(fp.d, v.d, rtol=0, atol=1e-9 * sc)
+    clear = np.abs(v.d[v.N[:v.nN]]) > 1e-8 * sc                # the sign of d decides the label only where d is not roundoff
+    np.testing.assert_array_equal(fp.Nb[clear], v.Nb[:v.nN][clear])
+    assert clear.mean() > 0.99
+    if clear.all():
+        np.testing.assert_allclose(fp.x, v.x, rtol=0, atol=1e-8 * sc)
