@@ -4990,10 +4990,11 @@ static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats
         }
         (void)service_maintenance_request(e);
         result = e->h_st->status == ST_RUNNING ? ELLP_MAXITER : status_message(*e->h_st, errbuf, errlen);
-        fill_stats(e, sp);
-        const uint64_t done = sp->iters - iters0;
+        // (the statistics — with the objective kernel and a synchronisation of their own — are filled once, after the loop)
+        const uint64_t done = e->h_st->iters - iters0;
         remaining = done < max_iters ? max_iters - done : 0;
     }
+    fill_stats(e, sp);
     if (e->nN == 0) result = ELLP_OPTIMAL;
     if (stats) stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return result;
