@@ -802,8 +802,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
             s_nh = 0;
             s_band = 0;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tmax = fmax(tmax, __shfl_xor(tmax, o));
+        tmax = wave_allmax_dpp(tmax);  // DPP butterfly + readlane (no NaN here: keys are never NaN)
         if (lane == 0) s_wk[wave] = tmax;
         lds_barrier();
         STAMP(1, 1);
