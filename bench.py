@@ -340,6 +340,10 @@ def roofline_of(meas, m, n, solver, world):
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc passes of an earlier run of this "
                                                    "command, not measured in this run)") if src else None,
+            "frac_of_measured_achievable": round(ach / 6290.0, 4),
+            "note": "peak = the 8 TB/s spec; /opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s as achievable by a pure "
+                    "streaming read.  The primal kernel's duration includes the ratio-test fold of the previous iteration in "
+                    "its prologue (two-launch pipeline), about 2.5 us before the first column is read.",
             "bytes_per_launch": meas["price_bytes"], "avg_us": round(t_us, 3),
             "avg_us_raw": round(t_us + prof.get("event_cost", {}).get("avg_us", 0.0), 3), "timing": EVENT_NOTE}
 
