@@ -123,6 +123,9 @@ struct DevState {
     // iteration's kernels do nothing) and pp_P such passes in a row are the optimality test
     int64_t pp_lo, pp_hi, pp_S;
     int32_t pp_P, pp_seg, pp_empty, pp_skip;
+    // ---- fused dual iterations (ellp_dualfu.inc): k_dual_fu number dp_seq has left the swap / scalars / next leaving
+    // row of its pivot to be done (~0: nothing is left); dp_applied = the last one the following pricing launch did
+    unsigned long long dp_seq, dp_applied;
 #ifdef ELLP_DBG_STAMPS
     long long dbg[3][4][8];  // [kernel][block selector][stamp] wall_clock64 (100 MHz) — dev builds only
 #endif
@@ -252,7 +255,163 @@ struct PriceArgs {
     int block0;             // first pricing block of this rank
     double eps;
     int pp_on;              // partial pricing: only positions [st->pp_lo, st->pp_hi) may enter
+    // dual engines whose fused iterations (ellp_dualfu.inc) are closed by the NEXT pricing launch instead of a block
+    // of their own: what that takes (dp_seq == 0: not this engine)
+    unsigned long long dp_seq;
+    const int32_t *dp_lrow;
+    const double *dp_ldelta, *dp_lside, *dp_d;
+    int dp_nrb;
+    double *dp_A_N, *dp_A_B, *dp_c_B, *dp_c_N, *dp_x, *dp_dd;
+    int64_t *dp_B_index, *dp_N_index;
+    uint8_t *dp_Nb;
+    Trace dp_trace;
 };
+
+// ---- closing a fused dual iteration (dual…:313-333 and the choice of the next leaving row, dual…:200-236)
+// the first row block of k_dual_fu that recorded a violation: its row (-1: none), delta and side; all 256 threads.
+// Row, delta and side of every record are fetched in ONE round trip, so that the choice does not cost a second
+// dependent one (this sits on the critical path of every pricing launch that closes a fused iteration).
+struct DualLeave {
+    long long lr;
+    double delta;
+    int side;
+};
+__device__ __forceinline__ DualLeave dual_first_violation(const int32_t *lrow, const double *ldelta, const double *lside, int nrb,
+                                                          int tid, long long *s_tmp) {
+    __shared__ double s_ld[4];
+    __shared__ int s_lr[4], s_ls[4];
+    const int lane = tid & 63, wave = tid >> 6;
+    int bb = 0x7fffffff, brow = -1, bside = 0;
+    double bdelta = 0.0;
+    for (int b0 = 0; b0 < nrb; b0 += 1024) {  // four records per thread in flight
+        int v[4];
+        double dl[4], sd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + tid + 256 * u;
+            const int bc = b < nrb ? b : 0;
+            v[u] = lrow[bc];
+            dl[u] = ldelta[bc];
+            sd[u] = lside[bc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b = b0 + tid + 256 * u;
+            if (b < nrb && v[u] >= 0 && b < bb) {
+                bb = b;
+                brow = v[u];
+                bdelta = dl[u];
+                bside = (int)sd[u];
+            }
+        }
+    }
+    const int wb = wave_allmin_dpp(bb);
+    if (bb == wb && wb != 0x7fffffff) {  // one lane per wave (the blocks a wave's lanes hold are distinct)
+        s_lr[wave] = brow;
+        s_ld[wave] = bdelta;
+        s_ls[wave] = bside;
+    }
+    if (lane == 0) s_tmp[wave] = wb;
+    lds_barrier();
+    int best = (int)s_tmp[0], bw = 0;
+    for (int w = 1; w < 4; ++w)
+        if ((int)s_tmp[w] < best) {
+            best = (int)s_tmp[w];
+            bw = w;
+        }
+    DualLeave o;
+    if (best == 0x7fffffff) {
+        o.lr = -1;
+        o.delta = 0.0;
+        o.side = 0;
+    } else {
+        o.lr = s_lr[bw];
+        o.delta = s_ld[bw];
+        o.side = s_ls[bw];
+    }
+    return o;
+}
+// the column / index / cost swap of the pivot (q, r); by all 256 threads of ONE block
+__device__ __forceinline__ void dual_close_swap(double *A_N, double *A_B, double *c_B, double *c_N, double *dd,
+                                                int64_t *N_index, uint8_t *Nb, const DevState *st, int64_t ld, int tid) {
+    const int64_t q = st->s_q, r = st->s_r, jq = st->s_jq, lv = st->s_lv;
+    const double theta_d = st->s_theta_d;
+    double2 *cn = reinterpret_cast<double2 *>(A_N + q * ld);
+    double2 *cb = reinterpret_cast<double2 *>(A_B + r * ld);
+    for (int64_t t = tid; t < (ld >> 1); t += 256) {
+        const double2 x = cn[t];
+        cn[t] = cb[t];
+        cb[t] = x;
+    }
+    if (tid == 0) {
+        dd[lv] = -theta_d;
+        dd[jq] = 0.0;
+        N_index[q] = lv;
+        Nb[q] = (uint8_t)st->s_side;
+    } else if (tid == 64) {
+        const double tc = c_N[q];
+        c_N[q] = c_B[r];
+        c_B[r] = tc;
+    }
+}
+// the scalars of the pivot and the next leaving row; by ONE thread
+__device__ __forceinline__ void dual_close_scalars(DevState *st, const double *d, double *x, int64_t *B_index, const Trace &trace,
+                                                   long long lr, double ldelta, int lside) {
+    const int64_t r = st->s_r, jq = st->s_jq;
+    const double theta_d = st->s_theta_d, delta = st->s_delta;
+    const double d_r = d[r];
+    const double theta_p = delta / d_r;
+    x[jq] = x[jq] + theta_p;
+    B_index[r] = jq;
+    const double obj = st->obj + theta_d * delta;
+    const unsigned long long it = st->iters + 1;
+    st->obj = obj;
+    st->cur = st->s_cur ^ 1;
+    st->pivots += 1;
+    st->iters = it;
+    trace_put(trace, it, obj);
+    if (d_r != d_r || theta_p != theta_p) st->status = ELLP_ERR_NAN;
+    st->lr = lr;
+    if (lr >= 0) {
+        st->ldelta = ldelta;
+        st->lside = lside;
+    }
+}
+// MODE 1 prologue of the pricing kernels: the leaving row, its delta and the current B^-1 buffer — from the state, or,
+// when the fused iteration in front of this launch is still open, from its records, finishing that iteration on the way
+// (the block that owns position q swaps the columns before it prices them; block 0 books the scalars)
+__device__ __forceinline__ void dual_price_prologue(const PriceArgs &a, DevState *st, int gb, int tid, long long *s_tmp,
+                                                    int64_t *lr_out, double *ldelta_out, int *cur_out) {
+    // everything the prologue reads from the state in one batch of loads (each separate test in front of a branch
+    // is a round trip of its own)
+    const unsigned long long open_seq = st->dp_seq;
+    const int64_t st_lr = st->lr, st_q = st->s_q;
+    const double st_ldelta = st->ldelta;
+    const int st_cur = st->cur, st_scur = st->s_cur;
+    __builtin_amdgcn_sched_barrier(0);
+    const bool pend = a.dp_seq != 0 && open_seq + 1 == a.dp_seq;
+    if (!pend) {
+        *lr_out = st_lr;
+        *ldelta_out = st_ldelta;
+        *cur_out = st_cur;
+        return;
+    }
+    const DualLeave lv = dual_first_violation(a.dp_lrow, a.dp_ldelta, a.dp_lside, a.dp_nrb, tid, s_tmp);
+    const long long lr = lv.lr;
+    const double ldelta = lv.delta;
+    const int lside = lv.side;
+    if ((int64_t)gb == st_q / a.cpb) {
+        dual_close_swap(a.dp_A_N, a.dp_A_B, a.dp_c_B, a.dp_c_N, a.dp_dd, a.dp_N_index, a.dp_Nb, st, a.ld, tid);
+        __syncthreads();  // the block prices the swapped column next
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        dual_close_scalars(st, a.dp_d, a.dp_x, a.dp_B_index, a.dp_trace, lr, ldelta, lside);
+        st->dp_applied = st->dp_seq;
+    }
+    *lr_out = lr;
+    *ldelta_out = ldelta;
+    *cur_out = st_scur ^ 1;
+}
 
 // 16-byte column load; NT = non-temporal.  When A_N is much larger than the 256 MiB Infinity Cache
 // (config 5: 1.4 GB) it is streamed once per iteration and should not displace B^-1, which the
@@ -292,7 +451,10 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     if (MODE == 0) {
         u2 = reinterpret_cast<const double2 *>(a.u);
     } else {
-        const int64_t lr = st->lr;
+        int64_t lr;
+        double ldelta;
+        int cur;
+        dual_price_prologue(a, st, a.block0 + (int)blockIdx.x, tid, s_p, &lr, &ldelta, &cur);
         if (lr < 0) {  // no primal-infeasible basic: optimal (dual…:243-246)
             if (blockIdx.x == 0 && tid == 0) {
                 st->iters += 1;
@@ -300,8 +462,8 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
             }
             return;
         }
-        sgn = (st->ldelta < 0.0) ? -1.0 : 1.0;
-        u2 = reinterpret_cast<const double2 *>((st->cur ? a.W1 : a.W0) + lr * a.ld);
+        sgn = (ldelta < 0.0) ? -1.0 : 1.0;
+        u2 = reinterpret_cast<const double2 *>((cur ? a.W1 : a.W0) + lr * a.ld);
     }
     double2 ur[T];
 #pragma unroll
@@ -462,7 +624,10 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
     if (MODE == 0) {
         u2 = reinterpret_cast<const double2 *>(a.u);
     } else {
-        const int64_t lr = st->lr;
+        int64_t lr;
+        double ldelta;
+        int cur;
+        dual_price_prologue(a, st, a.block0 + (int)blockIdx.x, tid, s_p, &lr, &ldelta, &cur);
         if (lr < 0) {  // no primal-infeasible basic: optimal (dual…:243-246)
             if (blockIdx.x == 0 && tid == 0) {
                 st->iters += 1;
@@ -470,8 +635,8 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
             }
             return;
         }
-        sgn = (st->ldelta < 0.0) ? -1.0 : 1.0;
-        u2 = reinterpret_cast<const double2 *>((st->cur ? a.W1 : a.W0) + lr * a.ld);
+        sgn = (ldelta < 0.0) ? -1.0 : 1.0;
+        u2 = reinterpret_cast<const double2 *>((cur ? a.W1 : a.W0) + lr * a.ld);
     }
     const int gb = a.block0 + (int)blockIdx.x;  // global pricing block
     const int64_t j0 = (int64_t)gb * a.cpb;
@@ -2414,6 +2579,9 @@ struct ellp_engine {
     bool obj_fresh = false;  // h_st->obj is c . x of the state in h_st (primal; see ellp_engine_run / fill_stats)
     bool lagged = false;    // two launches per primal iteration (ellp_lagged.inc)
     bool dual_fused = false;  // dual: FTRAN and eta update in one pass over B^-1 (ellp_dualfu.inc)
+    bool dual_fold = false;   // ... and its closing work done by the next pricing launch (no tiny-pivot maintenance)
+    bool dual_open = false;   // a fused iteration may still be open on the device (launch_dual_close)
+    unsigned long long dual_seq = 0;  // number of the dual iteration being enqueued
     bool lag_open = false;  // a k_ftran_eta has been enqueued whose ratio test no kernel has folded yet
     size_t price2_lds = 0;
     double *upart = nullptr, *y = nullptr, *dd = nullptr, *lam = nullptr, *resid = nullptr, *T = nullptr;
@@ -2644,6 +2812,14 @@ void launch_price(ellp_engine *e) {
     a.block0 = e->rank * e->nbs;
     a.eps = e->eps;
     a.pp_on = e->pp_P > 1 ? 1 : 0;
+    if (MODE == 1 && e->dual_fold) {
+        a.dp_seq = e->dual_seq;
+        a.dp_lrow = e->binfo; a.dp_ldelta = e->bmin; a.dp_lside = e->bmin + e->m; a.dp_d = e->d;
+        a.dp_nrb = (int)((e->m + UPD_ROWS - 1) / UPD_ROWS);
+        a.dp_A_N = e->A_N; a.dp_A_B = e->A_B; a.dp_c_B = e->c_B; a.dp_c_N = e->c_N; a.dp_x = e->x; a.dp_dd = e->dd;
+        a.dp_B_index = e->B_index; a.dp_N_index = e->N_index; a.dp_Nb = e->Nb;
+        a.dp_trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
+    }
     int mine = e->nblocks - a.block0;
     if (mine > e->nbs) mine = e->nbs;
     if (mine <= 0) mine = 1;  // empty shard (more ranks than pricing blocks): the block only serves DevState::tiny
@@ -2892,10 +3068,12 @@ void launch_resync(ellp_engine *e, int force) {
 // against the fresh inverse (launch_resync).  `reactive` (asked for by the device, or the follow-up of
 // such a request) is kept for diagnostics: resynchronising only then was tried and is worse (netlib
 // ADLITTLE / BLEND in 60 variable orders, dual: 4 wrong outcomes instead of 1).
+void launch_dual_close(ellp_engine *e);
 void maintain_inverse(ellp_engine *e, bool reactive = false, bool rebuild = false) {
     // two-launch pipeline: an open iteration (priced, FTRAN done, ratio test not folded) was decided with
     // the inverse that is about to be replaced — drop it; the next k_price2 starts afresh (use_pend = 0) and
     // the iteration is priced again from the maintained inverse.  Its eta-update half is already in B^-1.
+    launch_dual_close(e);  // a fused dual iteration is completed, not dropped: its pivot is in B^-1 already
     if (e->lagged) hipLaunchKernelGGL(k_drop_open, dim3(1), dim3(1), 0, e->stream, e->st);
     e->lag_open = false;
     if (rebuild) launch_refactor(e);
@@ -3057,7 +3235,9 @@ void launch_primal_iteration_lagged(ellp_engine *e) {
 
 // closing kernel of a slice: k_update2 folds the open iteration's ratio test, applies its eta update and
 // does its bookkeeping (the three-launch path's third kernel, unchanged)
+void launch_dual_close(ellp_engine *e);
 void launch_flush(ellp_engine *e) {
+    launch_dual_close(e);
     if (!e->lag_open) return;
     {
         Prof p(e, ELLP_K_UPDATE);
@@ -3096,34 +3276,42 @@ void launch_primal_iteration(ellp_engine *e) {
     e->enqueued += 1;
 }
 
-// FTRAN + eta update + x_B / d_N / y updates in one pass, then the closing block (ellp_dualfu.inc)
+// the closing block of the fused dual iteration in front (a no-op on the device if that has been closed already)
+void launch_dual_close(ellp_engine *e) {
+    if (!e->dual_open) return;
+    Prof p(e, ELLP_K_DUPDATE);
+    DualCloseArgs c{e->d, e->A_N, e->A_B, e->c_B, e->c_N, e->x, e->dd, e->B_index, e->N_index, e->Nb, e->binfo, e->bmin,
+                    e->bmin + e->m, (int)((e->m + UPD_ROWS - 1) / UPD_ROWS), e->st, e->m, e->ld, e->ill_tol,
+                    Trace{e->trace_obj, e->trace_it, e->trace_len}};
+    hipLaunchKernelGGL(k_dual_close, dim3(1), dim3(256), 0, e->stream, c);
+    e->dual_open = false;
+}
+
+// FTRAN + eta update + x_B / d_N / y updates in one pass (ellp_dualfu.inc); the iteration stays open
 void launch_dual_fu(ellp_engine *e) {
-    {
-        Prof p(e, ELLP_K_FTRAN);
-        DualFuArgs a{};
-        a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
-        a.N_index = e->N_index; a.B_index = e->B_index; a.x = e->x; a.d = e->d; a.y = e->y; a.dd = e->dd;
-        a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.lrow = e->binfo; a.ldelta = e->bmin; a.lside = e->bmin + e->m;
-        a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.eps = e->eps;
-        const dim3 g((unsigned)((e->m + UPD_ROWS - 1) / UPD_ROWS) + DFU_BOOK), b(256);
-        const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
-        if (nr <= 1) hipLaunchKernelGGL((k_dual_fu<1>), g, b, 0, e->stream, a);
-        else if (nr <= 2) hipLaunchKernelGGL((k_dual_fu<2>), g, b, 0, e->stream, a);
-        else if (nr <= 4) hipLaunchKernelGGL((k_dual_fu<4>), g, b, 0, e->stream, a);
-        else hipLaunchKernelGGL((k_dual_fu<8>), g, b, 0, e->stream, a);
-    }
-    {
-        Prof p(e, ELLP_K_DUPDATE);
-        DualCloseArgs c{e->d, e->A_N, e->A_B, e->c_B, e->c_N, e->x, e->dd, e->lb, e->ub, e->kindv, e->B_index, e->N_index,
-                        e->Nb, e->binfo, e->bmin, e->bmin + e->m, (int)((e->m + UPD_ROWS - 1) / UPD_ROWS), e->st, e->m, e->ld,
-                        e->ill_tol, e->eps, Trace{e->trace_obj, e->trace_it, e->trace_len}};
-        hipLaunchKernelGGL(k_dual_close, dim3(1), dim3(256), 0, e->stream, c);
-    }
+    Prof p(e, ELLP_K_FTRAN);
+    DualFuArgs a{};
+    a.W0 = e->W; a.W1 = e->W2; a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb};
+    a.N_index = e->N_index; a.B_index = e->B_index; a.x = e->x; a.d = e->d; a.y = e->y; a.dd = e->dd;
+    a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.lrow = e->binfo; a.ldelta = e->bmin; a.lside = e->bmin + e->m;
+    a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.eps = e->eps;
+    a.seq = e->dual_seq;
+    const dim3 g((unsigned)((e->m + UPD_ROWS - 1) / UPD_ROWS) + DFU_BOOK), b(256);
+    const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
+    if (nr <= 1) hipLaunchKernelGGL((k_dual_fu<1>), g, b, 0, e->stream, a);
+    else if (nr <= 2) hipLaunchKernelGGL((k_dual_fu<2>), g, b, 0, e->stream, a);
+    else if (nr <= 4) hipLaunchKernelGGL((k_dual_fu<4>), g, b, 0, e->stream, a);
+    else hipLaunchKernelGGL((k_dual_fu<8>), g, b, 0, e->stream, a);
+    e->dual_open = true;
 }
 
 void launch_dual_iteration(ellp_engine *e) {
+    e->dual_seq += 1;
     {
         Prof p(e, ELLP_K_DPRICE);
+        // closes the fused iteration in front of it if this engine folds the closing work (dual_fold) — unless it
+        // returns at entry on a stop, so the host keeps dual_open until a k_dual_close has been enqueued (which does
+        // nothing on the device when the iteration is closed already)
         launch_price<1>(e);
     }
     // the drift monitor compares A_B alpha_q with a_q between FTRAN and the update: those iterations keep the
@@ -3132,6 +3320,7 @@ void launch_dual_iteration(ellp_engine *e) {
     if (e->dual_fused && !drift_now) {
         if (e->drift_every > 0) e->since_drift += 1;
         launch_dual_fu(e);
+        if (!e->dual_fold) launch_dual_close(e);
         e->since_refactor += 1;
         e->enqueued += 1;
         return;
@@ -3617,6 +3806,8 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         init.r = -1;
         init.lr = -1;
         init.pp_hi = n_N;
+        init.dp_seq = ~0ull;
+        init.dp_applied = ~0ull;
         if (kind == ELLP_ENGINE_PRIMAL && e->opts.partial_segments > 1 && n_N > 0) {
             // partial pricing (f4): segments of ceil(|N| / P) positions, never more segments than positions
             int P = e->opts.partial_segments;
@@ -3714,6 +3905,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
                     (pl == 2 || (pl == 0 && m >= 384));  // partial pricing runs on the three-launch pipeline; tools/pipeline_threshold.py for the size
         e->dual_fused = !e->small && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 384));
+        e->dual_fold = e->dual_fused && e->ill_tol <= 0.0 && getenv("ELLP_DUAL_FOLD_OFF") == nullptr;
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
     }
@@ -3942,6 +4134,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                             else launch_dual_iteration(e);
                         }
                         to_launch -= batch;
+                        launch_dual_close(e);  // a batch ends on a complete state (a fused dual iteration may be open)
                         if (to_launch == 0 && e->kind == ELLP_ENGINE_PRIMAL) {
                             // the objective ellp_stats reports (c . x) rides on the last read-back instead of costing a
                             // launch and a synchronisation of its own after the loop (fill_stats)
@@ -3992,6 +4185,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             // this path serves the reactive maintenance of small LPs (and profiling): its follow-up refresh is
             // meant to come AFTER the iteration that follows a tiny pivot, so that iteration is completed here
             if (e->ill_tol > 0.0) launch_flush(e);
+            launch_dual_close(e);
             HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
             HIPCHK(hipStreamSynchronize(e->stream));
             HIPCHK(hipGetLastError());
