@@ -15,7 +15,8 @@ set) it is one of the ranks.  N ranks cooperate on ONE pivot stream: the nonbasi
 and pricing) are sharded, everything else is replicated ("scaling": "strong").
 
 Besides the headline workload (config 3, so that N=1 is comparable from round to round) every line
-carries a `config4` object (BASELINE.json's config 4: the same LP shape through the dual loop, N = 1 only) and
+carries a `config2` object (netlib AFIRO through the user API against the reference's known answer), a `config4`
+object (BASELINE.json's config 4: the same LP shape through the dual loop, N = 1 only) and
 a `config5` object: BASELINE.json's config 5 (m=4000, n=40000, primal), the one it names
 for 1/2/4/8 GPUs, run the same way — pivots/s, the pricing kernel's rate per GPU and its fraction
 of the HBM roofline.
@@ -393,6 +394,30 @@ def main():
               "kernels_us": {k: round(v["avg_us"], 3) for k, v in c4m["prof"].items()},
               "achieved_GBps_algorithmic": round(c4m["alg_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1)}
         del c4m
+    c2 = None
+    if is_c3 and world == 1:
+        # BASELINE.json's config 2: netlib AFIRO through the user API (parse_mps -> PrimalSimplexSolver::new(None).solve),
+        # objective against the reference's known answer (tests/problems/mod.rs:661)
+        try:
+            from ellp_amd import PrimalSimplexSolver, parse_mps
+            text = open(os.path.join(ROOT, "tests", "golden", "netlib", "afiro.mps")).read()
+            best, res = None, None
+            for rep in range(4):
+                prob = parse_mps(text)
+                t0 = time.perf_counter()
+                res = PrimalSimplexSolver.new(None).solve(prob)
+                dt2 = time.perf_counter() - t0
+                if rep:
+                    best = dt2 if best is None else min(best, dt2)
+            ref = -464.75314286
+            c2 = {"workload": "netlib AFIRO (27 x 32), primal simplex through the user API, both phases on one resident engine "
+                              "(the persistent one-workgroup kernel: an LU per iteration, bit for bit the CPU restatement)",
+                  "status": res.kind, "objective": res.solution.obj() if res.kind == "optimal" else None,
+                  "reference_objective": ref, "iterations_phase1_phase2": list(res.iters), "solve_ms": round(best * 1e3, 3)}
+            if c2["objective"] is not None:
+                c2["rel_diff"] = abs(c2["objective"] / ref - 1.0)
+        except Exception as ex:  # the headline must not depend on it
+            c2 = {"error": str(ex)[:200]}
     if ctx.dist is not None:
         ctx.dist.barrier()
         ctx.dist.destroy_process_group()
@@ -473,6 +498,8 @@ def main():
         lw = head["long_window"]
         lw["vs_value"] = round(lw["value"] / pivots_per_s, 4)
         out["long_window"] = lw
+    if c2 is not None:
+        out["config2"] = c2
     if c4 is not None:
         out["config4"] = c4
     if c5 is not None:
