@@ -111,10 +111,22 @@ __device__ __forceinline__ double sequential_sumsq(const double *x, int64_t len,
     double acc = 0.0;  // meaningful in thread 0
     for (int64_t c0 = 0; c0 < len; c0 += XCHUNK) {
         const int64_t n = (len - c0) < XCHUNK ? (len - c0) : XCHUNK;
-        for (int64_t k = tid; k < n; k += 256) s_x[k] = x[c0 + k];
+        for (int64_t k = tid; k < n; k += 256) {  // the squares are formed by all threads; only the additions are the chain
+            const double v = x[c0 + k];
+            s_x[k] = v * v;
+        }
         __syncthreads();
-        if (tid == 0)
-            for (int64_t k = 0; k < n; ++k) acc += s_x[k] * s_x[k];
+        if (tid == 0) {
+            int64_t k = 0;
+            for (; k + 8 <= n; k += 8) {  // eight LDS reads in flight in front of eight dependent additions
+                double q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = s_x[k + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += q[u];
+            }
+            for (; k < n; ++k) acc += s_x[k];
+        }
         __syncthreads();
     }
     if (tid == 0) *s_out = acc;
@@ -149,56 +161,66 @@ __global__ __launch_bounds__(256) void k_qr_reflect(double *xbuf, int64_t len, i
         for (int64_t r = tid; r < len; r += 256) xbuf[r] = xbuf[r] / n2;
 }
 
-// dot[j] = sum_r x[r] * M[i + r, j], one thread per trailing column j > i, accumulated in the host's
-// order; the loads of 32 consecutive rows are issued together, one batch ahead of the additions, so that the
-// sequential chain of adds is not also a chain of memory round trips.  Writes f2[j] = -2 * dot and clears the column's
-// pivot-search candidate for k_qr_update.
-constexpr int DOTB = 32;
+// dot[j] = sum_r x[r] * M[i + r, j] for every trailing column j > i, each accumulated by ONE lane in the host's order
+// (r ascending, multiply then add).  That fixes one accumulator per column, but not who fetches: a wave takes 16
+// columns, ALL 64 lanes fetch (lane = 16 s + c loads rows 4 u + s of column c: four 128-byte segments per load
+// instruction, 16 instructions = 64 rows in flight per wave), the tile goes through LDS, and lanes 0..15 do the
+// additions from there while the next tile's loads are already in flight.  (One lane per column with 64 columns per
+// wave left 62 waves on the whole device at config 5's shape and 0.5 TB/s: 2.3 ms per step.)
+// Writes f2[j] = -2 * dot and clears the column's pivot-search candidate for k_qr_update.
+constexpr int DOT_COLS = 16;   // columns per wave
+constexpr int DOT_ROWS = 64;   // rows per tile
 __global__ __launch_bounds__(64) void k_qr_dot(const double *A, int64_t m, int64_t nv, int64_t i, const double *xbuf,
                                                const QrState *st, double *f2, double *cand) {
-    const int64_t j = i + 1 + (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (j >= m) return;
-    cand[j] = 0.0;
+    __shared__ double s_t[2][DOT_ROWS][DOT_COLS];
+    __shared__ double s_x[2][DOT_ROWS];
+    const int lane = threadIdx.x, c = lane & 15, s = lane >> 4;
+    const int64_t j = i + 1 + (int64_t)blockIdx.x * DOT_COLS + c;
+    const bool colok = j < m;
+    if (lane < DOT_COLS && colok) cand[j] = 0.0;
     if (st->skip) {
-        f2[j] = 0.0;
+        if (lane < DOT_COLS && colok) f2[j] = 0.0;
         return;
     }
     const int64_t len = nv - i;
-    const double *cj = A + j + i * m;  // M[i + r, j] = cj[r * m]
+    const double *cj = A + (colok ? j : i + 1) + i * m;  // M[i + r, j] = cj[r * m]; clamped column: loaded, never used
     double dot = 0.0;
-    int64_t r0 = 0;
-    // software pipeline: the loads of batch b+1 are issued before the additions of batch b, so a wave always has
-    // 32-64 row loads in flight (the kernel has one wave per 64 columns: few waves, each must keep the memory busy)
-    double v[DOTB], xv[DOTB];
-    if (DOTB <= len) {
+    double v[DOT_ROWS / 4];
+    double xv = 0.0;
+    auto load_tile = [&](int64_t r0) {
 #pragma unroll
-        for (int k = 0; k < DOTB; ++k) {
-            v[k] = cj[k * m];
-            xv[k] = xbuf[k];
+        for (int u = 0; u < DOT_ROWS / 4; ++u) {
+            const int64_t r = r0 + 4 * u + s;
+            v[u] = cj[(r < len ? r : len - 1) * m];
         }
-    }
-    for (; r0 + DOTB <= len; r0 += DOTB) {
-        double vn[DOTB], xn[DOTB];
-        const bool more = r0 + 2 * DOTB <= len;
-        if (more) {
+        const int64_t rx = r0 + lane;
+        xv = xbuf[rx < len ? rx : len - 1];
+    };
+    auto store_tile = [&](int buf) {
 #pragma unroll
-            for (int k = 0; k < DOTB; ++k) {
-                vn[k] = cj[(r0 + DOTB + k) * m];
-                xn[k] = xbuf[r0 + DOTB + k];
+        for (int u = 0; u < DOT_ROWS / 4; ++u) s_t[buf][4 * u + s][c] = v[u];
+        s_x[buf][lane] = xv;
+    };
+    load_tile(0);
+    store_tile(0);
+    int buf = 0;
+    for (int64_t r0 = 0; r0 < len; r0 += DOT_ROWS) {
+        const bool more = r0 + DOT_ROWS < len;
+        if (more) load_tile(r0 + DOT_ROWS);  // in flight during the additions below
+        __builtin_amdgcn_wave_barrier();
+        const int n = (len - r0) < DOT_ROWS ? (int)(len - r0) : DOT_ROWS;
+        if (lane < DOT_COLS) {
+            if (n == DOT_ROWS) {
+#pragma unroll 8
+                for (int k = 0; k < DOT_ROWS; ++k) dot += s_x[buf][k] * s_t[buf][k][c];
+            } else {
+                for (int k = 0; k < n; ++k) dot += s_x[buf][k] * s_t[buf][k][c];
             }
         }
-#pragma unroll
-        for (int k = 0; k < DOTB; ++k) dot += xv[k] * v[k];
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < DOTB; ++k) {
-                v[k] = vn[k];
-                xv[k] = xn[k];
-            }
-        }
+        if (more) store_tile(buf ^ 1);  // one wave: LDS operations are in order, the other buffer's readers are done
+        buf ^= 1;
     }
-    for (; r0 < len; ++r0) dot += xbuf[r0] * cj[r0 * m];
-    f2[j] = -2.0 * dot;
+    if (lane < DOT_COLS && colok) f2[j] = -2.0 * dot;
 }
 
 // M[i + r, j] = f2[j] * x[r] + M[i + r, j] over the whole trailing block (element-wise: any order),
@@ -281,7 +303,7 @@ extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const doubl
         hipLaunchKernelGGL(k_qr_reflect, dim3(1), dim3(256), 0, stream, xbuf, nv - i, i, st, rdiag);
         if (i + 1 < m) {
             const int64_t ncol = m - i - 1, len = nv - i;
-            hipLaunchKernelGGL(k_qr_dot, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, stream, dA, m, nv, i, xbuf, st,
+            hipLaunchKernelGGL(k_qr_dot, dim3((unsigned)((ncol + DOT_COLS - 1) / DOT_COLS)), dim3(64), 0, stream, dA, m, nv, i, xbuf, st,
                                f2, cand);
             hipLaunchKernelGGL(k_qr_update, dim3((unsigned)((ncol + 255) / 256), (unsigned)((len + UPD_R - 1) / UPD_R)),
                                dim3(256), 0, stream, dA, m, nv, i, xbuf, st, f2, cand);
