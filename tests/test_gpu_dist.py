@@ -91,6 +91,8 @@ def _worker(rank, world, port, q):
         for seed in (300, 305, 311):
             cases.append((f"random-primal-{seed}", E.ENGINE_PRIMAL, lambda seed=seed: _random_flat(seed, "primal"), 150))
             cases.append((f"random-dual-{seed}", E.ENGINE_DUAL, lambda seed=seed: _random_flat(seed, "dual"), 150))
+        if world > 2:  # four ranks on one GPU: the primal cases (the dual is not column-sharded), one random LP
+            cases = [c for c in cases if c[1] == E.ENGINE_PRIMAL and c[0] not in ("random-primal-305", "random-primal-311")]
         for name, kind, make, cap in cases:
             opts = E.default_opts(max_iter=None, device=0, pipeline=1)  # the explicit-inverse engine on both sides
             ref_fp = make()
@@ -126,9 +128,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_engine_takes_the_same_pivots_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_engine_takes_the_same_pivots(world):
+    """world 2: every case and transport; world 4 (four processes on the one GPU, the card's process limit is 6): the
+    primal cases — shard boundaries that do not divide the pricing blocks evenly, a rank whose block is empty, the
+    mailbox with three peers"""
     import torch.multiprocessing as mp
-    world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -161,7 +166,8 @@ def test_sharded_engine_takes_the_same_pivots_world2():
                 full += r["info"]["full_exchanges"]
                 cols += r["info"]["column_requests"]
     # the degenerate random LPs must have driven the loop through its fall-back (ties below the gap) too
-    assert full > 0 and cols > 0, (full, cols)
+    if world == 2:
+        assert full > 0 and cols > 0, (full, cols)
 
 
 def test_stepped_api_world1_matches_run():
