@@ -480,3 +480,40 @@ def test_fused_dual_iteration_takes_the_same_pivots(m, n):
     st3, tr3, fp3 = solve(2, [1, 2, 3, 5], refactor_period=200)   # a period > 64 switches the drift monitor on
     assert st3 == E.OPTIMAL and tr3[-1][0] == tr1[-1][0]
     np.testing.assert_array_equal(tr3[-1][1], tr1[-1][1])
+
+
+@pytest.mark.parametrize("kind_name", ["primal", "dual"])
+def test_back_to_back_slices_equal_one_long_run(kind_name):
+    """ellp_engine_run called again and again with nothing in between (the second and later calls start without a
+    read-back of the state: the previous call left the host copy current) against one long run, and against slices
+    with other calls in between (which make the next run read the state back first): same iteration counts, same
+    bases, to the same optimum"""
+    E = _engine()
+    from ellp_amd import synth
+    if kind_name == "primal":
+        f, kind = synth.primal_phase1_flat(20260301, 420, 1000), E.ENGINE_PRIMAL
+    else:
+        f, kind = synth.dual_start_flat(20260301, 420, 1000), E.ENGINE_DUAL
+
+    def solve(slice_len, touch):
+        fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"],
+                           f["Nb"], f.get("y"), f.get("d"))
+        eng = E.Engine(kind, fp, E.default_opts(max_iter=None))
+        st, calls = E.MAXITER, 0
+        while st == E.MAXITER:
+            st, stats, msg = eng.run(slice_len)
+            calls += 1
+            if touch and calls % 3 == 0:
+                eng.inverse_residual()          # any other call: the next run must not trust the host copy
+            assert calls < 100000
+        eng.read_point()
+        it = int(stats.iters)
+        eng.close()
+        return st, it, fp
+    st0, it0, fp0 = solve(1 << 40, False)
+    st1, it1, fp1 = solve(23, False)
+    st2, it2, fp2 = solve(23, True)
+    assert st0 == st1 == st2 == E.OPTIMAL
+    assert it0 == it1 == it2
+    np.testing.assert_array_equal(fp0.B, fp1.B)
+    np.testing.assert_array_equal(fp0.B, fp2.B)
