@@ -3423,6 +3423,11 @@ void ellp_default_opts(ellp_opts *o) {
     o->device = -1;
 }
 
+#ifdef ELLP_BL_STAMPS
+int ellp_debug_bl_stamps(unsigned long long *out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bl_stamps), 8 * sizeof(unsigned long long));
+}
+#endif
 int ellp_hip_abi_version(void) { return ELLP_HIP_ABI_VERSION; }
 
 int ellp_hip_device_count(void) {
