@@ -46,6 +46,20 @@ def build_engine(force=False, verbose=False):
     return ENGINE_LIB
 
 
+ENGINE_DBG_LIB = os.path.join(HERE, "libellp_hip_dbg.so")
+
+
+def build_engine_debug(force=False, verbose=False):
+    """the same engine with -DELLP_DEBUG_BOUNDS (index assertions at every committed decision); tests load it through
+    ELLP_HIP_LIB in a child process"""
+    if force or _stale(ENGINE_DBG_LIB, _deps(ENGINE_SRC)):
+        cmd = [HIPCC] + HIPFLAGS + ["-DELLP_DEBUG_BOUNDS"] + ENGINE_SRC + ["-o", ENGINE_DBG_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return ENGINE_DBG_LIB
+
+
 def build_host(force=False, verbose=False):
     if not os.path.isdir(HOST_DIR):
         return None
@@ -63,10 +77,12 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
-def build_all(force=False, verbose=False):
+def build_all(force=False, verbose=False, debug_bounds=False):
     build_engine(force, verbose)
     build_host(force, verbose)
+    if debug_bounds:
+        build_engine_debug(force, verbose)
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, verbose=True)
+    build_all(force="--force" in sys.argv, verbose=True, debug_bounds="--debug-bounds" in sys.argv)

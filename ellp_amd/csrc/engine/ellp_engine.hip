@@ -158,6 +158,24 @@ __device__ __forceinline__ void trace_put(const Trace &t, unsigned long long ite
     t.it[k] = iters;
 }
 
+// Debug build with bounds assertions (`python -m ellp_amd.build --debug-bounds` -> libellp_hip_dbg.so,
+// selected with ELLP_HIP_LIB): every index a decision commits (entering position, leaving row, variable indices) is
+// checked against its range by the thread that commits it; a violation stops the loop with ELLP_ERR_PANIC and the
+// code of the check.  Compiled out of the product build.
+#ifdef ELLP_DEBUG_BOUNDS
+#define ELLP_CHECK(st, cond, code)               \
+    do {                                         \
+        if (!(cond)) {                           \
+            (st)->panic_code = (code);           \
+            (st)->status = ELLP_ERR_PANIC;       \
+        }                                        \
+    } while (0)
+#else
+#define ELLP_CHECK(st, cond, code) \
+    do {                           \
+    } while (0)
+#endif
+
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -1196,6 +1214,8 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     }
     STAMP(1, 3);
     if (blockIdx.x == 0 && tid == 0) {  // commit the decision for k_update2
+        ELLP_CHECK(st, q >= 0 && q < a.nN, 9101);
+        ELLP_CHECK(st, MODE == 0 || (st->lr >= 0 && st->lr < a.m), 9102);
         st->s_cur = cur;
         st->s_q = q;
         st->s_at_lower = at_lower;
@@ -1638,6 +1658,11 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
 
     // ---------------- bookkeeping block(s)
     const int64_t jq = st->s_jq;
+    if (blockIdx.x == 0 && tid == 0) {
+        ELLP_CHECK(st, r >= -1 && r < m, 9103);
+        ELLP_CHECK(st, q >= 0 && q < a.nN, 9104);
+        ELLP_CHECK(st, jq >= 0, 9105);
+    }
     // A pivot that is tiny next to the rest of its column makes the basis ill-conditioned for a
     // while and leaves O(cond * eps) error in B^-1 that the eta updates then carry along, where
     // the reference's per-iteration LU would forget it at once.  On small LPs (a refresh is a few
@@ -3352,6 +3377,7 @@ ellp_status status_message(const DevState &s, char *errbuf, size_t errlen) {
         if (s.panic_code == 402) set_err(errbuf, errlen, "assertion failed: lambda >= 0.");
         else if (s.panic_code == 229) set_err(errbuf, errlen, "pivot should have been unbounded");
         else if (s.panic_code == 293) set_err(errbuf, errlen, "assertion failed: reduced cost of a nonbasic variable has the wrong sign (dual phase 2 construction)");
+        else if (s.panic_code >= 9100 && s.panic_code < 9200) set_err(errbuf, errlen, "debug build: an index left its range (check %d)", s.panic_code);
         else if (s.panic_code == 201) set_err(errbuf, errlen, "bounds should always be fixed or two-sided");
         else if (s.panic_code == 187) set_err(errbuf, errlen, "unwrap() on None in BTRAN");
         else if (s.panic_code == 295) set_err(errbuf, errlen, "unwrap() on None in FTRAN");
