@@ -2551,6 +2551,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
 #include "ellp_shard.inc"
 #include "ellp_rebuild.inc"
 #include "ellp_small.inc"
+#include "ellp_mid.inc"
 
 }  // namespace
 
@@ -2652,6 +2653,13 @@ struct ellp_engine {
     size_t slab_size = 0, slab_used = 0;
     unsigned long long *small_stamps = nullptr;  // ELLP_SMALL_STAMPS: per-phase tick sums of k_small, printed at destroy
     int small_nt = SMALL_THREADS;  // workgroup size of k_small for this LP (small_threads)
+    // 128 < m <= 1024: the same loop with its factors in global memory (ellp_mid.inc); `small` is set as well, so
+    // that everything that asks "is there an explicit inverse" keeps working unchanged
+    bool mid = false;
+    size_t mid_lds = 0;
+    int mid_nt = 0;
+    int64_t ldn = 0;
+    double *LUa = nullptr, *Ut = nullptr, *A_Nt = nullptr;
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
     int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
@@ -3527,16 +3535,23 @@ void ellp_engine_destroy(ellp_engine *e) {
     }
 #endif
     if (e->small_stamps) {
-        unsigned long long t[10] = {0};
+        unsigned long long t[32] = {0};
         if (hipMemcpy(t, e->small_stamps, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess && t[8] > 0) {
-            static const char *nm[8] = {"leaving row", "copy A_B", "LU", "BTRAN", "pricing", "entering fold", "FTRAN",
-                                        "ratio test + updates"};
-            fprintf(stderr, "k_small m=%lld nN=%lld threads=%d, us per iteration over %llu iterations:", (long long)e->m,
-                    (long long)e->nN, e->small_nt, t[8]);
+            static const char *nm_s[8] = {"leaving row", "copy A_B", "LU", "BTRAN", "pricing", "entering fold", "FTRAN",
+                                          "ratio test + updates"};
+            static const char *nm_m[8] = {"leaving row", "LU", "BTRAN U^T", "BTRAN L^T", "pricing", "entering fold + FTRAN",
+                                          "ratio test + updates", "-"};
+            const char **nm = e->mid_lds > 0 && e->small_lds == 0 ? nm_m : nm_s;
+            fprintf(stderr, "%s m=%lld nN=%lld threads=%d, us per iteration over %llu iterations:", nm == nm_m ? "k_mid" : "k_small",
+                    (long long)e->m, (long long)e->nN, nm == nm_m ? e->mid_nt : e->small_nt, t[8]);
             for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.2f;", nm[k], (double)t[k] / 100.0 / (double)t[8]);
             double tot = 0.0;
             for (int k = 0; k < 8; ++k) tot += (double)t[k];
             fprintf(stderr, " total %.2f; shader clock %.0f MHz\n", tot / 100.0 / (double)t[8], (double)t[9] / (tot / 100.0));
+            if (nm == nm_m)
+                fprintf(stderr, "   LU: panel load %.2f; 16 steps %.2f; store + publish %.2f; pivot rows of the trailing columns %.2f; trailing update %.2f\n",
+                        (double)t[10] / 100.0 / (double)t[8], (double)t[11] / 100.0 / (double)t[8], (double)t[12] / 100.0 / (double)t[8],
+                        (double)t[13] / 100.0 / (double)t[8], (double)t[14] / 100.0 / (double)t[8]);
         }
     }
     e->stream = e->own_stream;
@@ -3551,6 +3566,18 @@ void ellp_engine_destroy(ellp_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     host_set_release(e->host_set);
     delete e;
+}
+
+// the instantiation of k_mid for an engine kind and a workgroup size
+static const void *mid_kernel(int kind, int nt) {
+    if (kind == ELLP_ENGINE_PRIMAL) {
+        if (nt == 256) return reinterpret_cast<const void *>(&k_mid<0, 256>);
+        if (nt == 512) return reinterpret_cast<const void *>(&k_mid<0, 512>);
+        return reinterpret_cast<const void *>(&k_mid<0, 1024>);
+    }
+    if (nt == 256) return reinterpret_cast<const void *>(&k_mid<1, 256>);
+    if (nt == 512) return reinterpret_cast<const void *>(&k_mid<1, 512>);
+    return reinterpret_cast<const void *>(&k_mid<1, 1024>);
 }
 
 // the instantiation of k_small for an engine kind and a workgroup size
@@ -3903,25 +3930,49 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     {
         const int pl = e->opts.pipeline;
         e->small_lds = small_lds_bytes(m, n_N);
+        e->mid_lds = mid_lds_bytes(m, n_N);
+        // up to which size the exact loop is the DEFAULT (it is 20-80 x slower per iteration than the explicit-inverse
+        // engine at these sizes, and the only one that ends as the reference does on ill-conditioned LPs)
+        int64_t mid_auto = 512;
+        if (const char *ev = getenv("ELLP_MID_AUTO_MAX")) mid_auto = atoll(ev);
+        const bool fits = e->small_lds > 0 || e->mid_lds > 0;
         const bool wanted = e->pp_P <= 1 && (pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
-                                                         e->opts.profile == 0));
-        if (pl == 3 && e->small_lds == 0) {
-            set_err(errbuf, errlen, "pipeline 3 (one persistent workgroup) needs m <= %d and its LU in LDS", SMALL_MAX_M);
+                                                         e->opts.profile == 0 && (m <= SMALL_MAX_M || m <= mid_auto)));
+        if (pl == 3 && !fits) {
+            set_err(errbuf, errlen, "pipeline 3 (one persistent workgroup, LU every iteration) needs m <= %d", MID_MAX_M);
             ellp_engine_destroy(e);
             return ELLP_ERR_ARG;
         }
-        e->small = wanted && e->small_lds > 0;
-        if (e->small) {
+        e->small = wanted && fits;
+        e->mid = e->small && e->small_lds == 0;
+        if (e->small && getenv("ELLP_SMALL_STAMPS") && !e->small_stamps) {
+            if (dmalloc(e, &e->small_stamps, 32) == hipSuccess) (void)hipMemsetAsync(e->small_stamps, 0, 256, e->stream);
+            else e->small_stamps = nullptr;
+        }
+        if (e->mid) {
+            e->mid_nt = mid_threads(m);
+            e->ldn = (n_N + 15) / 16 * 16;
+            const void *fn = mid_kernel(e->kind, e->mid_nt);
+            hipError_t ra = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->mid_lds);
+            if (ra == hipSuccess) ra = dmalloc(e, &e->LUa, (size_t)(ld * ld));
+            if (ra == hipSuccess) ra = dmalloc(e, &e->Ut, (size_t)(ld * ld));
+            if (ra == hipSuccess) ra = dmalloc(e, &e->A_Nt, (size_t)(ld * e->ldn));
+            if (ra != hipSuccess) {
+                (void)hipGetLastError();
+                if (pl == 3) {
+                    set_err(errbuf, errlen, "pipeline 3: no device memory for the factors of the persistent-workgroup loop");
+                    ellp_engine_destroy(e);
+                    return ELLP_ERR_DEVICE;
+                }
+                e->small = e->mid = false;  // the large engine handles it
+            }
+        } else if (e->small) {
             int nt = small_threads(m, n_N);
             if (const char *ev = getenv("ELLP_SMALL_NT")) {  // measurement: force a workgroup size that still has a thread per row
                 const int v = atoi(ev);
                 if ((v == 64 || v == 128 || v == 256) && v >= m) nt = v;
             }
             e->small_nt = nt;
-            if (getenv("ELLP_SMALL_STAMPS") && !e->small_stamps) {
-                if (dmalloc(e, &e->small_stamps, 16) == hipSuccess) (void)hipMemsetAsync(e->small_stamps, 0, 128, e->stream);
-                else e->small_stamps = nullptr;
-            }
             const void *fn = small_kernel(e->kind, nt);
             hipError_t ra = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->small_lds);
             if (ra != hipSuccess) {
@@ -4033,18 +4084,37 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
     uint64_t remaining = max_iters;
     const int64_t per = (int64_t)e->nbs * e->cpb;  // layout of the pricing buffer (Xchg, one segment)
     while (remaining > 0) {
-        SmallArgs a{};
-        a.A_B = e->A_B; a.A_N = e->A_N; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
-        a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
-        a.kbuf = e->X + 2 * e->nbs;
-        a.rbuf = e->X + 2 * e->nbs + per;
-        a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
-        a.max_iters = remaining < 16384 ? remaining : 16384;
-        a.nch = (int)((e->nN + 63) / 64);
-        a.eps = e->eps;
-        a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
-        a.stamps = e->small_stamps;
-        {
+        if (e->mid) {
+            MidArgs a{};
+            a.A_B = e->A_B; a.A_N = e->A_N; a.A_Nt = e->A_Nt; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+            a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+            a.kbuf = e->X + 2 * e->nbs;
+            a.rbuf = e->X + 2 * e->nbs + per;
+            a.LUa = e->LUa; a.Ut = e->Ut;
+            a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.ldn = e->ldn;
+            a.max_iters = remaining < 4096 ? remaining : 4096;
+            a.nch = (int)((e->nN + 63) / 64);
+            a.eps = e->eps;
+            a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
+            a.stamps = e->small_stamps;
+            // the row-major copy of A_N the pricing pass reads: made afresh at every launch (anything may have
+            // touched A_N in between: a hand-off, a sharding call, the other engine)
+            hipLaunchKernelGGL(k_mid_transpose, dim3((unsigned)((e->m + 31) / 32), (unsigned)((e->nN + 31) / 32)), dim3(256), 0,
+                               e->stream, e->A_N, e->A_Nt, e->m, e->ld, e->nN, e->ldn);
+            void *kargs[] = {&a};
+            HIPCHK(hipLaunchKernel(mid_kernel(e->kind, e->mid_nt), dim3(1), dim3((unsigned)e->mid_nt), kargs, e->mid_lds, e->stream));
+        } else {
+            SmallArgs a{};
+            a.A_B = e->A_B; a.A_N = e->A_N; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+            a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+            a.kbuf = e->X + 2 * e->nbs;
+            a.rbuf = e->X + 2 * e->nbs + per;
+            a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
+            a.max_iters = remaining < 16384 ? remaining : 16384;
+            a.nch = (int)((e->nN + 63) / 64);
+            a.eps = e->eps;
+            a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
+            a.stamps = e->small_stamps;
             void *kargs[] = {&a};
             HIPCHK(hipLaunchKernel(small_kernel(e->kind, e->small_nt), dim3(1), dim3((unsigned)e->small_nt), kargs,
                                    e->small_lds, e->stream));

@@ -127,3 +127,29 @@ def collect_results(q, procs, world, timeout):
             if len(results) < world:
                 raise RuntimeError(f"a rank died (exit codes {dead}) before reporting; {len(results)} of {world} results")
     return results
+
+
+def blockdiag(fx, copies):
+    """`copies` independent copies of an LP as ONE problem (block-diagonal constraints, summed objective): its
+    optimum is copies x the LP's, its bases are block-diagonal arrangements of the LP's own (ill-conditioned)
+    bases — the way to get real, sparse, degenerate LPs with more than 128 rows out of the reference's three
+    netlib fixtures (tests/problems/mod.rs:657-674), at a size the LU-per-iteration oracle still solves."""
+    n = len(fx["vars"])
+    out = {"vars": [], "constraints": []}
+    for k in range(copies):
+        out["vars"] += [[obj, list(bound)] for obj, bound in fx["vars"]]
+        out["constraints"] += [[[[j + k * n, a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in fx["constraints"]]
+    return out
+
+
+def permuted_fixture(fx, rng):
+    """The same LP with its variables and constraints in another order (the reference builds its problems by
+    iterating HashMaps, tests/problems/mod.rs:657-674, so every order occurs)."""
+    import numpy as np
+    n = len(fx["vars"])
+    perm = rng.permutation(n)            # new index k holds old variable perm[k]
+    inv = np.empty(n, dtype=int)
+    inv[perm] = np.arange(n)
+    rows = [fx["constraints"][i] for i in rng.permutation(len(fx["constraints"]))]
+    return {"vars": [fx["vars"][j] for j in perm],
+            "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
