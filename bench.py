@@ -24,6 +24,7 @@ of the HBM roofline.
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -65,6 +66,9 @@ def parse():
                     help="1/0: also run config 4 (m=2000 n=5000, dual simplex) on one GPU and report it as `config4` "
                          "(-1: yes when the headline is config 3 and N = 1)")
     ap.add_argument("--config4-steps", type=int, default=2000)
+    ap.add_argument("--config4-reference", type=int, default=1,
+                    help="1/0: also time the dual loop on the reference's own DualPhase1 arrays of the config-3 LP "
+                         "(`config4_reference_phase1`; ~15 s of setup)")
     ap.add_argument("--long-window", type=int, default=3000,
                     help="when --steps < 1000: additionally time a window of this many steps (0 off)")
     return ap.parse_args()
@@ -199,7 +203,32 @@ def pmc_traffic(m, n, solver, dual):
     return None, None
 
 
-def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_window=0):
+def rocprof_avg_us(kernel_prefixes):
+    """average duration of the dominant kernel in the newest committed rocprofv3 --kernel-trace --stats summary of
+    this command (profiles/*default_kernel_stats.csv), with the file it came from — so that roofline.frac can be
+    recomputed from the line alone"""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*default_kernel_stats.csv")), reverse=True):
+        try:
+            rows = list(csv.DictReader(open(f)))
+        except Exception:
+            continue
+        for row in rows:
+            name = row.get("Name") or row.get("KernelName") or ""
+            mm = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", name)
+            short = mm.group(1) if mm else ""
+            if any(short.startswith(px) for px in kernel_prefixes):
+                try:
+                    avg_ns = float(row.get("AverageNs") or row.get("Average") or 0.0)
+                except ValueError:
+                    continue
+                if avg_ns > 0:
+                    return round(avg_ns / 1e3, 3), short, os.path.relpath(f, ROOT)
+    return None, None, None
+
+
+def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_window=0, flat_override=None):
     """One workload on this process group: W warm-up steps, K timed steps bracketed by barrier +
     synchronize on both sides (max over ranks), an optional longer window, per-kernel event times from
     a second run, and — sharded — the self-check against a single-GPU replay."""
@@ -209,7 +238,7 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
     torch = ctx.torch
     world, rank = ctx.world, ctx.rank
     dual = solver == "dual"
-    flat = synth.dual_start_flat(seed, m, n) if dual else synth.primal_phase1_flat(seed, m, n)
+    flat = flat_override or (synth.dual_start_flat(seed, m, n) if dual else synth.primal_phase1_flat(seed, m, n))
 
     def make_fp():
         return E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"],
@@ -229,8 +258,11 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
 
     def make_engine(profile, f=None):
         if world > 1:
+            # the column-sharded loop runs the three-launch kernels; say so explicitly, so that the single-GPU replay
+            # of the self-check below can be built with the same pipeline (the two-launch pipeline sums the FTRAN dot
+            # products in another order: a tie could fall the other way and read as a divergence)
             from ellp_amd.dist import ShardedEngine
-            return ShardedEngine(kind, f or fp, opts_for(profile))
+            return ShardedEngine(kind, f or fp, opts_for(profile, pipeline=0))
         return E.Engine(kind, f or fp, opts_for(profile))
 
     # ---- timed region: tableau resident, W warm-up steps, then exactly K steps
@@ -274,7 +306,7 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
         same_as_single = None
         if rank == 0:
             fp1 = make_fp()
-            ref = E.Engine(kind, fp1, opts_for(0))
+            ref = E.Engine(kind, fp1, opts_for(0, pipeline=0))  # three launches, like the sharded loop
             ref.run(total_after)
             ref.read_point()
             ref.close()
@@ -321,6 +353,11 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
         price_cols = a1 - a0
     out["price_bytes"] = 8.0 * ld * price_cols
     out["alg_bytes_per_pivot"] = 8.0 * ld * nN + (24.0 if dual else 32.0) * m * ld
+    # what the engine really moves per pivot: one pass over A_N, and ONE pass over B^-1 that reads and rewrites it
+    # (two-launch forms, m >= 384: the eta update is fused with FTRAN; BTRAN is an O(m) update of u) — three-launch
+    # form: + 8 m ld for the separate FTRAN read
+    two_pass = m >= 384 and world == 1 and args.pipeline != 0
+    out["engine_bytes_per_pivot"] = 8.0 * ld * nN + (16.0 if two_pass else 24.0) * m * ld
     # what the engine moves per iteration: BTRAN is O(m) incremental, and with the two-kernel pipeline
     # the eta update and the next FTRAN share one pass over B^-1
     return out
@@ -337,7 +374,13 @@ def roofline_of(meas, m, n, solver, world):
         traffic, src = pmc_traffic(m, n, solver, dual)
     t_us = prof[pk]["avg_us"]
     ach = meas["price_bytes"] / (t_us * 1e-6) / 1e9
+    rp_us, rp_name, rp_file = (None, None, None)
+    if world == 1 and (m, n) == (2000, 5000) and not dual:
+        rp_us, rp_name, rp_file = rocprof_avg_us(["k_price2_wave"])
     return {"kernel": "pricing pass of one GPU (k_price*<%d>)" % (1 if dual else 0), "bound": "hbm",
+            "avg_us_rocprof": rp_us, "avg_us_rocprof_kernel": rp_name,
+            "avg_us_rocprof_source": (rp_file + " (rocprofv3 --kernel-trace --stats of an earlier run of this command)") if rp_file else None,
+            "frac_rocprof": round(meas["price_bytes"] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp_us else None,
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc passes of an earlier run of this "
                                                    "command, not measured in this run)") if src else None,
@@ -381,6 +424,7 @@ def main():
                   "pricing_GBps_all_gpus": round(r5["achieved"] * world, 1) if r5 else None,
                   "roofline": r5, "kernels_us": {k: round(v["avg_us"], 3) for k, v in c5m["prof"].items()},
                   "achieved_GBps_algorithmic": round(c5_bytes * c5m["steps"] / c5m["dt"] / 1e9, 1),
+                  "engine_GBps": round(c5m["engine_bytes_per_pivot"] * c5m["steps"] / c5m["dt"] / 1e9, 1),
                   "sharded_check": c5m.get("sharded_check")}
         del c5m
     c4 = None
@@ -392,8 +436,42 @@ def main():
               "value": round(c4m["steps"] / c4m["dt"], 2), "unit": "pivots/s", "steps": c4m["steps"],
               "ms_per_step": round(1e3 * c4m["dt"] / c4m["steps"], 6), "roofline": r4,
               "kernels_us": {k: round(v["avg_us"], 3) for k, v in c4m["prof"].items()},
-              "achieved_GBps_algorithmic": round(c4m["alg_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1)}
+              "achieved_GBps_algorithmic": round(c4m["alg_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1),
+              "engine_GBps": round(c4m["engine_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1)}
         del c4m
+    c4ref = None
+    if (args.config4 == 1 or (args.config4 < 0 and is_c3)) and world == 1 and args.config4_reference:
+        # config 4 on the reference's OWN dual phase-1 arrays (dual_problem.rs:89-256: the box problem of the config-3 LP,
+        # basis from the LU of A^T, nonbasics at lower / upper by the sign of d), built by this repository's host mirror
+        # of ellp's setup (DualPhase1::from_problem: rank check and LU of A^T on the device, the rest on the host)
+        try:
+            import numpy as np
+            from ellp_amd import Bound, ConstraintOp, Problem, synth
+            t0 = time.perf_counter()
+            A, b, c = synth.dense_lp(args.seed, 2000, 5000)
+            p = Problem()
+            ids = [p.add_var(float(c[j]), Bound.Lower(0.0)) for j in range(5000)]
+            for i in range(2000):
+                p.add_constraint(list(zip(ids, A[i].tolist())), ConstraintOp.Lte, float(b[i]))
+            f = p._debug_phase1("dual")
+            t_setup = time.perf_counter() - t0
+            flat4 = {"m": f["m"], "n": f["n"], "n_c": f["n_c"], "A": f["A"], "c": f["c"], "b": f["b"], "kind": f["kind"],
+                     "lb": f["lb"], "ub": f["ub"], "x": f["x"], "B": f["B"], "N": f["N"], "Nb": f["Nb"], "y": f["y"], "d": f["d"]}
+            c4r = measure(ctx, args, 2000, 5000, args.seed, "dual", args.config4_steps, 200, min(args.profile_steps, 100),
+                          flat_override=flat4)
+            r4r = roofline_of(c4r, 2000, 5000, "dual", 1)
+            nb = np.bincount(np.asarray(f["Nb"], dtype=np.int64), minlength=3)
+            c4ref = {"workload": f"dual phase 1 of the config-3 LP exactly as the reference builds it (dual_problem.rs:89-256): box "
+                                 f"problem 2000x{c4r['n_cols']}, every variable TwoSided, |N|={c4r['nN']} with {int(nb[0])} nonbasics at "
+                                 f"their lower and {int(nb[1])} at their upper bound, basis from the LU of A^T",
+                     "value": round(c4r["steps"] / c4r["dt"], 2), "unit": "pivots/s", "steps": c4r["steps"],
+                     "ms_per_step": round(1e3 * c4r["dt"] / c4r["steps"], 6), "roofline": r4r,
+                     "kernels_us": {k: round(v["avg_us"], 3) for k, v in c4r["prof"].items()},
+                     "engine_GBps": round(c4r["engine_bytes_per_pivot"] * c4r["steps"] / c4r["dt"] / 1e9, 1),
+                     "setup_s": round(t_setup, 1)}
+            del c4r, flat4, f
+        except Exception as ex:  # the headline must not depend on it
+            c4ref = {"error": str(ex)[:300]}
     c2 = None
     if is_c3 and world == 1:
         # BASELINE.json's config 2: netlib AFIRO through the user API (parse_mps -> PrimalSimplexSolver::new(None).solve),
@@ -486,11 +564,18 @@ def main():
                    "sharded_check": head.get("sharded_check"),
                    "mailbox_failed_fell_back_to_rccl": bool(head.get("mailbox_failed", False))},
         "achieved_GBps_algorithmic": round(alg_gbps, 1),
-        "iteration_roofline": {"bytes_per_step_algorithmic": alg_bytes_per_pivot,
-                               "achieved": round(alg_gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(alg_gbps / HBM_PEAK_GBS, 4),
-                               "note": "SURVEY.md §8d bytes per pivot (8 m |N| + 32 m^2 primal, + 24 m^2 dual) / "
-                                       "ms_per_step; the engine itself moves less (BTRAN is an O(m) update)"},
+        "iteration_roofline": {"bytes_per_step_engine": head["engine_bytes_per_pivot"],
+                               "achieved": round(head["engine_bytes_per_pivot"] * steps / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(head["engine_bytes_per_pivot"] * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
+                               "note": "THE quoted fraction: bytes the engine really moves per pivot (8 ld |N| for the pricing "
+                                       "pass + 16 m ld for the one pass that reads and rewrites B^-1; 24 m ld on the three-launch "
+                                       "form) / ms_per_step / 8 TB/s.  PMC traffic of every kernel equals these bytes within 2 % "
+                                       "(profiles/).",
+                               "survey_bytes_per_step": alg_bytes_per_pivot,
+                               "survey_frac": round(alg_gbps / HBM_PEAK_GBS, 4),
+                               "survey_note": "SURVEY.md §8d's figure (8 m |N| + 32 m^2 primal, 24 m^2 dual: a B^-1 GEMV for BTRAN, "
+                                              "one for FTRAN, a read + write for the update) counts bytes this engine no longer "
+                                              "moves; kept for comparison with earlier rounds, not a claim"},
         "roofline": roofline, "cpu_baseline": cpu,
         "kernels_us": {k: round(v["avg_us"], 3) for k, v in prof.items()}, "kernels_us_note": EVENT_NOTE,
     }
@@ -502,6 +587,8 @@ def main():
         out["config2"] = c2
     if c4 is not None:
         out["config4"] = c4
+    if c4ref is not None:
+        out["config4_reference_phase1"] = c4ref
     if c5 is not None:
         out["config5"] = c5
     if cpu:

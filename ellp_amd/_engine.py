@@ -28,7 +28,7 @@ class Opts(C.Structure):
                 ("refactor_period", C.c_int32), ("btran_mode", C.c_int32),
                 ("poll_interval", C.c_int32), ("profile", C.c_int32), ("use_graph", C.c_int32),
                 ("pipeline", C.c_int32), ("trace_len", C.c_int32), ("partial_segments", C.c_int32),
-                ("reserved", C.c_int32 * 1)]
+                ("flags", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -345,7 +345,10 @@ class Engine:
         err = C.create_string_buffer(512)
         s = lib().ellp_engine_read_point(self._h, _p(fp.x), _p(fp.B), _p(fp.N), _p(fp.Nb), _p(fp.y),
                                          _p(fp.d), err, 512)
-        if s != OPTIMAL:
+        # OPTIMAL: delivered; UNBOUNDED / ERR_PANIC / ERR_NAN: delivered, and completing the iteration the two-launch
+        # pipeline had left open ended the solve that way (include/ellp_hip.h)
+        self.closing_status = s
+        if s in (ERR_DEVICE, ERR_ARG, ERR_BAD_DIMS):
             raise EllpHipError(s, err.value.decode())
         return fp
 

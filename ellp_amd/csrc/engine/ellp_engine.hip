@@ -223,6 +223,37 @@ __device__ __forceinline__ int wave_allmin_dpp(int v) {
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// one wave per column: a column with exactly one nonzero entry is recorded under its variable's index
+__global__ __launch_bounds__(256) void k_scan_singletons(const double *A, int64_t ld, int64_t m, int64_t ncols, const int64_t *index,
+                                                         int32_t *vs_row, double *vs_val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= ncols) return;
+    const double *c = A + j * ld;
+    int cnt = 0, row = -1;
+    double val = 0.0;
+    for (int64_t i = lane; i < m; i += 64) {
+        const double v = c[i];
+        if (v != 0.0) {  // a NaN counts: such a column is never a unit column
+            cnt += (v == v) ? 1 : 2;
+            row = (int)i;
+            val = v;
+        }
+    }
+    int tot = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    const unsigned long long has = __ballot(cnt > 0);
+    if (tot == 1) {
+        const int l = __ffsll((long long)has) - 1;
+        if (lane == l) {
+            const int64_t v = index[j];
+            vs_row[v] = row;
+            vs_val[v] = val;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ pricing output / exchange buffer
 // The pricing kernels write their per-column and per-block results into ONE buffer laid out in
 // `world` equal segments, one per rank (world = 1 on a single GPU):
@@ -273,6 +304,15 @@ struct PriceArgs {
     int block0;             // first pricing block of this rank
     double eps;
     int pp_on;              // partial pricing: only positions [st->pp_lo, st->pp_hi) may enter
+    // unit columns ("sparse A", first step).  Every LP in standard form carries them: a slack per
+    // inequality row (standard_form.rs:115-136) and, in phase 1, an artificial per row (primal_problem.rs:236-246) —
+    // 29-57 % of the nonbasic columns of config 3.  vs_row[v] = the row of variable v's ONLY nonzero (-1: a general
+    // column), vs_val[v] its value; made once per engine from the matrix (k_scan_singletons; the matrix never
+    // changes, positions do: the table is indexed by VARIABLE, N_index leads to it).  The primal pricing kernels
+    // form such a column's dot product as vs_val * u[vs_row] instead of streaming 8 ld bytes of zeros — the same
+    // number the stream gives (every other term is an exact zero), so the pivots are the same.  null: off.
+    const int32_t *vs_row;
+    const double *vs_val;
     // dual engines whose fused iterations (ellp_dualfu.inc) are closed by the NEXT pricing launch instead of a block
     // of their own: what that takes (dp_seq == 0: not this engine)
     unsigned long long dp_seq;
@@ -505,6 +545,15 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     double best = (MODE == 0) ? -INFINITY : INFINITY;
     long long bestpos = -1;
     int buf = 0;
+    // unit columns (PriceArgs::vs_row): every wave fetches the flags of the block's columns itself (lane l: column j0 + l)
+    const bool use_vs = MODE == 0 && a.vs_row != nullptr;
+    int sgl = -1;
+    double svl = 0.0;
+    if (use_vs && j0 + lane < j1) {
+        const int64_t v = a.N_index[j0 + lane];
+        sgl = a.vs_row[v];
+        svl = a.vs_val[v];
+    }
     for (int64_t j = j0; j < j1; j += 4, buf ^= 1) {
         const int ncol = (int)((j1 - j) < 4 ? (j1 - j) : 4);
         // epilogue inputs of the (up to 4) column-owner threads: issued before the column stream
@@ -516,29 +565,53 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
             nb_pre = a.Nb[jo];
             cd_pre = (MODE == 0) ? a.c_N[jo] : a.dd[a.N_index[jo]];
         }
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        const double2 *col[4];
+        int sg[4] = {-1, -1, -1, -1};
+        bool all_unit = use_vs;
+        int dense0 = -1;  // a general column of the group: unit columns are pointed at it (no traffic of their own)
+        if (use_vs) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t jj = (j + k < j1) ? j + k : j1 - 1;  // clamp: stay in bounds, no branch
-            col[k] = reinterpret_cast<const double2 *>(a.A_N + jj * a.ld);
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int64_t idx = tid + 256 * t;
-            if (idx < half) {
-                double2 v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = load_col2<NT>(col[k] + idx);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    acc[k] = fma(v[k].x, ur[t].x, acc[k]);
-                    acc[k] = fma(v[k].y, ur[t].y, acc[k]);
+            for (int k = 0; k < 4; ++k) {
+                if (k < ncol) {
+                    sg[k] = __builtin_amdgcn_readlane(sgl, (int)(j - j0) + k);
+                    if (sg[k] < 0) {
+                        all_unit = false;
+                        if (dense0 < 0) dense0 = k;
+                    }
                 }
             }
         }
+        // the column-owner threads (tid < ncol, all in wave 0): their own column's flag, value and entry of u
+        // (the shuffles run on all lanes: a lane that sits out cannot be read from)
+        const int sg_sh = __shfl(sgl, ((int)(j - j0) + (tid & 3)) & 63);
+        const double my_sv = __shfl(svl, ((int)(j - j0) + (tid & 3)) & 63);
+        const int my_sg = (use_vs && tid < ncol) ? sg_sh : -1;
+        const double u_unit = my_sg >= 0 ? reinterpret_cast<const double *>(u2)[my_sg] : 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (!all_unit) {
+            const double2 *col[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = wave_sum(acc[k]);
+            for (int k = 0; k < 4; ++k) {
+                int64_t jj = (j + k < j1) ? j + k : j1 - 1;  // clamp: stay in bounds, no branch
+                if (use_vs && k < ncol && sg[k] >= 0) jj = j + dense0;
+                col[k] = reinterpret_cast<const double2 *>(a.A_N + jj * a.ld);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int64_t idx = tid + 256 * t;
+                if (idx < half) {
+                    double2 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = load_col2<NT>(col[k] + idx);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[k] = fma(v[k].x, ur[t].x, acc[k]);
+                        acc[k] = fma(v[k].y, ur[t].y, acc[k]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = wave_sum(acc[k]);
+        }
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) s_part[buf][wave][k] = acc[k];
@@ -546,8 +619,9 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
         __syncthreads();
         if (tid < ncol) {
             const int k = tid;
-            const double dot =
+            double dot =
                 ((s_part[buf][0][k] + s_part[buf][1][k]) + s_part[buf][2][k]) + s_part[buf][3][k];
+            if (my_sg >= 0) dot = my_sv * u_unit;
             const int64_t jj = j + k;
             const int nb = nb_pre;
             if (MODE == 0) {
@@ -671,6 +745,15 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
     }
     double best = (MODE == 0) ? -INFINITY : INFINITY;  // lanes 0 and 1 own the pair's two columns
     long long bestpos = -1;
+    // unit columns (PriceArgs::vs_row): lane l holds the flag of column j0 + l
+    const bool use_vs = MODE == 0 && a.vs_row != nullptr;
+    int sgl = -1;
+    double svl = 0.0;
+    if (use_vs && j0 + lane < j1) {
+        const int64_t v = a.N_index[j0 + lane];
+        sgl = a.vs_row[v];
+        svl = a.vs_val[v];
+    }
     for (int64_t j = j0 + 2 * wave; j < j1; j += 8) {
         const int ncol = (j1 - j) < 2 ? 1 : 2;
         int nb_pre = 0;
@@ -680,10 +763,15 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
             nb_pre = a.Nb[jo];
             cd_pre = (MODE == 0) ? a.c_N[jo] : a.dd[a.N_index[jo]];
         }
-        const double2 *c0 = reinterpret_cast<const double2 *>(a.A_N + j * a.ld);
-        const double2 *c1 = reinterpret_cast<const double2 *>(a.A_N + (j + 1 < j1 ? j + 1 : j) * a.ld);
+        const int64_t jb_ = (j + 1 < j1 ? j + 1 : j);
+        const int s0 = use_vs ? __builtin_amdgcn_readlane(sgl, (int)(j - j0)) : -1;
+        const int s1 = use_vs ? __builtin_amdgcn_readlane(sgl, (int)(jb_ - j0)) : -1;
+        const bool stream = !(s0 >= 0 && s1 >= 0);
+        // a unit column next to a general one is pointed at its neighbour: no traffic of its own
+        const double2 *c0 = reinterpret_cast<const double2 *>(a.A_N + ((s0 >= 0) ? jb_ : j) * a.ld);
+        const double2 *c1 = reinterpret_cast<const double2 *>(a.A_N + ((s1 >= 0) ? j : jb_) * a.ld);
         double acc0 = 0.0, acc1 = 0.0;
-        for (int64_t t0 = lane; t0 < half; t0 += 4 * WAVE) {
+        for (int64_t t0 = lane; stream && t0 < half; t0 += 4 * WAVE) {
             double2 uu[4], v0[4], v1[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -702,8 +790,12 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
                 acc1 = fma(v1[k].y, uu[k].y, acc1);
             }
         }
-        acc0 = wave_sum(acc0);
-        acc1 = wave_sum(acc1);
+        if (stream) {
+            acc0 = wave_sum(acc0);
+            acc1 = wave_sum(acc1);
+        }
+        if (s0 >= 0) acc0 = readlane_f64(svl, (int)(j - j0)) * reinterpret_cast<const double *>(u2)[s0];
+        if (s1 >= 0) acc1 = readlane_f64(svl, (int)(jb_ - j0)) * reinterpret_cast<const double *>(u2)[s1];
         if (lane < ncol) {
             const double dot = lane == 0 ? acc0 : acc1;
             const int64_t jj = j + lane;
@@ -2653,6 +2745,10 @@ struct ellp_engine {
     size_t slab_size = 0, slab_used = 0;
     unsigned long long *small_stamps = nullptr;  // ELLP_SMALL_STAMPS: per-phase tick sums of k_small, printed at destroy
     int small_nt = SMALL_THREADS;  // workgroup size of k_small for this LP (small_threads)
+    // unit columns (PriceArgs::vs_row): per VARIABLE, made once at creation; null = the pricing kernels stream everything
+    int32_t *vs_row = nullptr;
+    double *vs_val = nullptr;
+    int64_t unit_columns = 0;  // how many variables have one (diagnostics)
     // 128 < m <= 1024: the same loop with its factors in global memory (ellp_mid.inc); `small` is set as well, so
     // that everything that asks "is there an explicit inverse" keeps working unchanged
     bool mid = false;
@@ -2845,6 +2941,8 @@ void launch_price(ellp_engine *e) {
     a.block0 = e->rank * e->nbs;
     a.eps = e->eps;
     a.pp_on = e->pp_P > 1 ? 1 : 0;
+    a.vs_row = MODE == 0 ? e->vs_row : nullptr;
+    a.vs_val = MODE == 0 ? e->vs_val : nullptr;
     if (MODE == 1 && e->dual_fold) {
         a.dp_seq = e->dual_seq;
         a.dp_lrow = e->binfo; a.dp_ldelta = e->bmin; a.dp_lside = e->bmin + e->m; a.dp_d = e->d;
@@ -3188,6 +3286,7 @@ void launch_price2(ellp_engine *e, int use_pend) {
     a.p.A_N = e->A_N; a.p.W0 = e->W; a.p.W1 = e->W2; a.p.u = nullptr; a.p.c_N = e->c_N; a.p.Nb = e->Nb;
     a.p.N_index = e->N_index; a.p.dd = nullptr; a.p.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.p.st = e->st;
     a.p.ld = e->ld; a.p.nN = e->nN; a.p.cpb = e->cpb; a.p.block0 = e->rank * e->nbs; a.p.eps = e->eps;
+    a.p.vs_row = e->vs_row; a.p.vs_val = e->vs_val;
     a.u0 = e->u; a.u1 = e->u + e->ld; a.W0 = e->W; a.W1 = e->W2;
     a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bsec = e->bmin + e->m; a.bidx = e->bidx; a.binfo = e->binfo; a.dpos = e->dpos;
     a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
@@ -3925,6 +4024,21 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
             }
         }
     }
+    // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the primal
+    // pricing kernels consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
+    if (kind == ELLP_ENGINE_PRIMAL && n_N > 0 && !(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr) {
+        if (dmalloc(e, &e->vs_row, (size_t)n_c) == hipSuccess && dmalloc(e, &e->vs_val, (size_t)n_c) == hipSuccess) {
+            ECHK(hipMemsetAsync(e->vs_row, 0xff, sizeof(int32_t) * (size_t)n_c, e->stream));
+            hipLaunchKernelGGL(k_scan_singletons, dim3((unsigned)((n_N + 3) / 4)), dim3(256), 0, e->stream, e->A_N, e->ld, m, n_N,
+                               e->N_index, e->vs_row, e->vs_val);
+            hipLaunchKernelGGL(k_scan_singletons, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, e->stream, e->A_B, e->ld, m, m,
+                               e->B_index, e->vs_row, e->vs_val);
+        } else {
+            (void)hipGetLastError();
+            e->vs_row = nullptr;
+            e->vs_val = nullptr;
+        }
+    }
     // small LPs: the reference's own loop in one persistent workgroup (ellp_small.inc) unless the caller
     // asked for the explicit-inverse engine (a maintenance period, a launch structure, profiling)
     {
@@ -4302,6 +4416,22 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
         }
     }
+    // The caller's budget (ellp_opts.max_iter) is spent: the reference has run that many FULL loop bodies
+    // (primal…:162-202), so an unbounded ray, a panic or a NaN found by the ratio test of the last one is its
+    // result, not MaxIter.  On the two-launch pipeline that ratio test is still open (its fold belongs to the next
+    // pricing launch, which will not come): close it and take the status from behind the closing kernel.  Slices
+    // inside the budget stay open — that is what makes slicing free.
+    if (result == ELLP_MAXITER && e->lag_open && !e->small && e->world == 1 && e->h_st->iters >= e->opts.max_iter) {
+        launch_flush(e);
+        hipLaunchKernelGGL(k_primal_obj, dim3(1), dim3(1024), 0, e->stream, e->c_B, e->c_N, e->x, e->B_index, e->N_index, e->m,
+                           e->nN, e->st);
+        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        reconcile_counters(e);
+        adopt_fin(e);
+        e->obj_fresh = true;
+        if (e->h_st->status != ST_RUNNING && e->h_st->status != ST_NEED_MAINT) result = status_message(*e->h_st, errbuf, errlen);
+    }
     if (stats) {
         fill_stats(e, stats);
         stats->t_loop_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -4320,7 +4450,9 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, 
     if (e) e->hst_fresh = false;  // anything but ellp_engine_run may change the device state behind h_st
     if (!e) return ELLP_ERR_ARG;
     HIPCHK(hipSetDevice(e->device));
+    const bool was_open = e->lag_open;
     launch_flush(e);  // two-launch pipeline: fold and book the iteration that is still open
+    if (was_open) HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     if (x) HIPCHK(hipMemcpyAsync(x, e->x, sizeof(double) * (size_t)e->n_c, hipMemcpyDeviceToHost, e->stream));
     if (B_index) HIPCHK(hipMemcpyAsync(B_index, e->B_index, sizeof(int64_t) * (size_t)e->m, hipMemcpyDeviceToHost, e->stream));
     if (N_index && e->nN) HIPCHK(hipMemcpyAsync(N_index, e->N_index, sizeof(int64_t) * (size_t)e->nN, hipMemcpyDeviceToHost, e->stream));
@@ -4330,6 +4462,13 @@ ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index, 
         if (d) HIPCHK(hipMemcpyAsync(d, e->dd, sizeof(double) * (size_t)e->n_c, hipMemcpyDeviceToHost, e->stream));
     }
     HIPCHK(hipStreamSynchronize(e->stream));
+    if (was_open) {
+        // completing the open iteration may have ended the solve (its ratio test found an unbounded ray, a panic of
+        // the reference, a NaN): that status is reported here, with the point as it stands
+        adopt_fin(e);
+        const int32_t stt = e->h_st->status;
+        if (stt != ST_RUNNING && stt != ST_NEED_MAINT && stt != ELLP_OPTIMAL) return status_message(*e->h_st, errbuf, errlen);
+    }
     return ELLP_OPTIMAL;
 }
 
@@ -4804,6 +4943,18 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
     ns.lr = -1;
     *e->h_st = ns;
     DCHK(hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+    // y, d and the labels are made from B^-1 and checked against the reference's EPS assertions (dual_problem.rs:275-323);
+    // the reference takes a FRESH LU there, so the resident inverse (up to a maintenance period of eta updates old) is
+    // rebuilt from A_B first — once per solve
+    launch_dual_close(e);
+    launch_refactor(e);
+    DCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    DCHK(hipStreamSynchronize(e->stream));
+    if (e->h_st->status != ST_RUNNING) {
+        cleanup();
+        return status_message(*e->h_st, errbuf, errlen);
+    }
+    e->since_refactor = 0;
     const ellp_status ps = dual_point_from_inverse(e, c_dev, 0, Nsorted.data(), errbuf, errlen);
     cleanup();
 #undef DCHK

@@ -153,6 +153,10 @@ struct DualPhase2 {  // :69-73
     // in variable order with placeholder labels, x / y / d zero — for the device hand-off
     // (ellp_engine_dual_rephase), which fills them in
     static DualPhase2 shell_from_phase1(DualPhase1 phase_1);
+    // the linear algebra of from_phase1 on a shell (dual_problem.rs:275-350: LU of A_B, y, d, labels, x): what the host
+    // falls back to when the device hand-off is not available (an engine of the LU-per-iteration kind keeps no
+    // inverse) or trips one of the reference's EPS assertions on its inexact inverse
+    void point_on_host();
 };
 
 enum class SolutionStatus { Optimal, Infeasible, Unbounded, MaxIter };  // src/solver.rs:27-33

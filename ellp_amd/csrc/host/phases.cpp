@@ -269,16 +269,15 @@ std::optional<DualPhase1> DualPhase1::from_problem(Problem prob, bool defer_poin
 
 // dual_problem.rs:258-404
 DualPhase2 DualPhase2::from_phase1(DualPhase1 phase_1) {
-    const Problem &phase_1_prob = phase_1.std_form.prob;
-    StandardForm std_form = std::move(phase_1.orig_std_form);
+    DualPhase2 p2 = shell_from_phase1(std::move(phase_1));
+    p2.point_on_host();
+    return p2;
+}
+
+void DualPhase2::point_on_host() {
+    std::vector<Basic> B = std::move(point.point.B);
     std::vector<char> is_basic(std_form.cols(), 0);
-    std::vector<Basic> B;
-    for (const auto &b : phase_1.point.point.B) {
-        const size_t index = phase_1_prob.variables[b.index].id;
-        is_basic[index] = 1;
-        B.push_back({index});
-    }
-    DualPhase2 p2;
+    for (const auto &b : B) is_basic[b.index] = 1;
     if (!B.empty()) {
         if (static_cast<Index>(B.size()) != std_form.A.rows) throw EllPPanic("basis size does not match the row count");
         dense::LU A_B_lu(std_form.A.select_columns(basic_columns(B)));
@@ -310,7 +309,7 @@ DualPhase2 DualPhase2::from_phase1(DualPhase1 phase_1) {
         std::vector<double> x_B = dense::b_minus_Av(std_form.A, x, std_form.b);  // basics are still 0 in x
         if (!A_B_lu.solve(x_B)) throw EllPPanic("called `Option::unwrap()` on a `None` value");
         for (size_t i = 0; i < B.size(); ++i) x[B[i].index] = x_B[i];
-        p2.point = DualFeasiblePoint{std::move(y), std::move(d), Point{std::move(x), std::move(N), std::move(B)}};
+        point = DualFeasiblePoint{std::move(y), std::move(d), Point{std::move(x), std::move(N), std::move(B)}};
     } else {
         std::vector<double> x_N(static_cast<size_t>(std_form.A.cols), 0.0);
         std::vector<Nonbasic> N;
@@ -325,10 +324,8 @@ DualPhase2 DualPhase2::from_phase1(DualPhase1 phase_1) {
             case Bound::Fixed: x_N[i] = bd.lb; N.push_back({i, NonbasicBound::Lower}); break;
             }
         }
-        p2.point = DualFeasiblePoint{{}, std_form.c, Point{std::move(x_N), std::move(N), std::move(B)}};
+        point = DualFeasiblePoint{{}, std_form.c, Point{std::move(x_N), std::move(N), std::move(B)}};
     }
-    p2.std_form = std::move(std_form);
-    return p2;
 }
 
 DualPhase2 DualPhase2::shell_from_phase1(DualPhase1 phase_1) {

@@ -111,10 +111,10 @@ SolutionStatus run_resident(ellp_engine *e, std::uint64_t max_iter, Flat &f, Poi
     char err[512] = {0};
     const ellp_status s = ellp_engine_run(e, max_iter, &st, err, sizeof(err));
     if (iters) *iters = st.iters;
-    const SolutionStatus out = to_status(s, err);
+    SolutionStatus out = to_status(s, err);
     const ellp_status rs = ellp_engine_read_point(e, pt.x.data(), f.B.data(), f.N.data(), f.Nb.data(), nullptr,
                                                   nullptr, err, sizeof(err));
-    if (rs != ELLP_OPTIMAL) to_status(rs, err);
+    if (rs != ELLP_OPTIMAL) out = to_status(rs, err);  // an error, or the status the still open last iteration ended in
     unflatten(f, pt);
     return out;
 }
@@ -222,10 +222,10 @@ SolutionStatus run_resident_dual(ellp_engine *e, std::uint64_t max_iter, Flat &f
     char err[512] = {0};
     const ellp_status s = ellp_engine_run(e, max_iter, &st, err, sizeof(err));
     if (iters) *iters = st.iters;
-    const SolutionStatus out = to_status(s, err);
+    SolutionStatus out = to_status(s, err);
     const ellp_status rs = ellp_engine_read_point(e, dp.point.x.data(), f.B.data(), f.N.data(), f.Nb.data(), dp.y.data(),
                                                   dp.d.data(), err, sizeof(err));
-    if (rs != ELLP_OPTIMAL) to_status(rs, err);
+    if (rs != ELLP_OPTIMAL) out = to_status(rs, err);
     unflatten(f, dp.point);
     return out;
 }
@@ -302,8 +302,21 @@ SolverResult DualSimplexSolver::solve(Problem prob) const {
         char err[512] = {0};
         const ellp_status rs = ellp_engine_dual_rephase(eng.e, phase_2.std_form.c.data(), phase_2.std_form.b.data(),
                                                         f2.kind.data(), f2.lb.data(), f2.ub.data(), err, sizeof(err));
-        if (rs != ELLP_OPTIMAL) to_status(rs, err);  // the reference's assertions on the sign of d come back as panics
-        s2 = run_resident_dual(eng.e, max_iter_, f2, phase_2.point, &res.iters_phase2);
+        if (rs == ELLP_OPTIMAL) {
+            s2 = run_resident_dual(eng.e, max_iter_, f2, phase_2.point, &res.iters_phase2);
+        } else if (rs == ELLP_ERR_ARG || rs == ELLP_ERR_PANIC) {
+            // no hand-off on this engine (the LU-per-iteration kind keeps no inverse), or one of the reference's EPS
+            // assertions on the sign of d tripped on the device's inverse, which is not the fresh LU the reference
+            // takes (dual_problem.rs:275-284): do the hand-off as the reference does, on the host — if the assertion
+            // is the reference's own it fires again there, as the panic it is
+            ellp_engine_destroy(eng.e);
+            eng.e = nullptr;
+            phase_2.point_on_host();
+            s2 = solve_with_initial(phase_2.std_form, phase_2.point, &res.iters_phase2);
+        } else {
+            to_status(rs, err);
+            return res;
+        }
     } else {
         if (eng.e) {  // phase 1 ran on a resident engine whose matrix is not phase 2's
             ellp_engine_destroy(eng.e);

@@ -58,6 +58,7 @@ enum { ELLP_BOUND_FREE = 0, ELLP_BOUND_LOWER = 1, ELLP_BOUND_UPPER = 2, ELLP_BOU
 enum { ELLP_NB_LOWER = 0, ELLP_NB_UPPER = 1, ELLP_NB_FREE = 2 };
 
 #define ELLP_MAX_ITER_NONE UINT64_MAX /* PrimalSimplexSolver::new(None), primal…:26-30 */
+#define ELLP_FLAG_DENSE_PRICING 1      /* ellp_opts.flags */
 
 typedef struct ellp_opts {
     uint64_t max_iter;       /* self.max_iter (primal…:16, dual…:17); default 1000 (:21) */
@@ -83,7 +84,9 @@ typedef struct ellp_opts {
                                  entering rule; a pass that finds no candidate moves to the next segment (and counts
                                  as an iteration), `segments` such passes in a row are the optimality test.  Primal
                                  engines on one GPU, three-launch pipeline.  0 or 1: every column every iteration */
-    int32_t reserved[1];
+    int32_t flags;           /* bit 0 (ELLP_FLAG_DENSE_PRICING): stream every nonbasic column in the primal pricing pass,
+                                also the unit columns (slacks, artificials), whose dot product the kernels otherwise
+                                form from their single entry — same numbers, measured both ways by bench.py */
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */
@@ -189,6 +192,14 @@ ellp_status ellp_engine_create_primal_phase1(
 ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats,
                             char *errbuf, size_t errbuf_len);
 
+/* ellp_engine_run(e, K) runs up to K loop bodies.  On the two-launch primal pipeline (m >= 384) a slice leaves the
+ * ratio test of its last iteration to the next slice's first kernel; when the slice spends the caller's whole budget
+ * (ellp_opts.max_iter loop bodies since the engine was made or re-phased) that iteration is completed before the
+ * status is taken, so that — as in the reference, which runs max_iter FULL loop bodies (primal…:162-202) — an
+ * unbounded ray found in the last permitted iteration is reported as ELLP_UNBOUNDED, not ELLP_MAXITER.
+ * ellp_engine_read_point completes an open iteration too; it returns ELLP_OPTIMAL when the point was delivered and the
+ * loop can go on (or had ended), otherwise the status that completing the open iteration produced (ELLP_UNBOUNDED,
+ * ELLP_ERR_PANIC, ELLP_ERR_NAN): the arrays are filled in either case. */
 ellp_status ellp_engine_read_point(ellp_engine *e, double *x, int64_t *B_index,
                                    int64_t *N_index, uint8_t *N_bound, double *y, double *d,
                                    char *errbuf, size_t errbuf_len);

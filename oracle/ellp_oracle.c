@@ -1122,7 +1122,6 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
         int have = 0;
         double r1 = 0.0;
         int64_t q = -1;
-        int nan_seen = 0;
         const int64_t pp_lo = pp_P > 1 ? (int64_t)pp_seg * pp_S : 0;
         const int64_t pp_hi = pp_P > 1 ? (pp_lo + pp_S < nN ? pp_lo + pp_S : nN) : nN;
         for (int64_t j = pp_lo; j < pp_hi; ++j) {
@@ -1154,11 +1153,9 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
                 q = j;
             }
         }
-        if (nan_seen) {
-            set_err(err, errlen, "NaN detected");
-            status = EO_ERR_NAN;
-            break;
-        }
+        /* No "NaN detected" exit here: the expect() of :282 sits behind the '>= EPS' test, which is false for a NaN
+         * operand, so the reference orders a NaN key by variable index and goes on (the engine stops with
+         * ELLP_ERR_NAN instead — a documented deviation, pinned by tests/test_gpu_abi_edge.py). */
         if (!have) { /* :289-292 */
             if (pp_P > 1 && pp_empty + 1 < pp_P) { /* nothing in this segment: on to the next one */
                 pp_seg = (pp_seg + 1) % pp_P;

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of GPU time (config 5 solved to optimality); skipped unless ELLP_SLOW=1")
 
 
 def _gpu_available():
@@ -21,6 +22,11 @@ def _gpu_available():
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get("ELLP_SLOW") != "1":
+        slow = pytest.mark.skip(reason="slow: minutes of GPU time; run with ELLP_SLOW=1 (result of the last run: profiles/)")
+        for item in items:
+            if "slow" in item.keywords:
+                item.add_marker(slow)
     if _gpu_available():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

@@ -37,12 +37,31 @@ def test_all_columns_basic_is_optimal():
     assert st == E.OPTIMAL and stats.iters == 0
 
 
-def test_nan_in_data_is_reported():
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_nan_in_data_is_reported(pipeline):
+    """A NaN in a nonbasic column.  A documented DEVIATION, pinned on both sides: the reference's "NaN detected"
+    expect() (primal…:282) is unreachable — a NaN operand fails the `>= EPS` test in front of it — so its max_by
+    orders the NaN key by variable index, the column enters, the ratio test sees no finite ratio and the loop
+    returns Unbounded after one iteration (the oracle does exactly that); the engine refuses to pivot on a NaN and
+    returns ELLP_ERR_NAN from the same iteration."""
+    from oracle import ellp_oracle as eo
     E = _E()
     A = np.array([[1.0, 1.0, 1.0, 0.0], [1.0, np.nan, 0.0, 1.0]])
     fp = _tiny(E, A, np.array([-1.0, -1.0, 0.0, 0.0]), np.array([0, 0, 1.0, 1.0]), [2, 3], [0, 1], [0, 0])
-    st, _, msg = E.primal_solve_with_initial(fp)
-    assert st in (E.ERR_NAN, E.ERR_SINGULAR, E.ERR_PANIC), (st, msg)
+
+    class V:
+        pass
+    v = V()
+    v.m, v.n, v.n_c, v.nB, v.nN = 2, 4, 4, 2, 2
+    v.A, v.c, v.b = fp.A.copy(), fp.c.copy(), fp.b.copy()
+    v.kind, v.lb, v.ub, v.x = fp.kind.copy(), fp.lb.copy(), fp.ub.copy(), fp.x.copy()
+    v.B, v.N, v.Nb = fp.B.copy(), fp.N.copy(), fp.Nb.copy()
+    st_o, it_o, _ = eo.primal_solve_with_initial(v, 100)
+    assert (st_o, it_o) == (eo.UNBOUNDED, 1)
+    st, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=100, pipeline=pipeline))
+    assert st == E.ERR_NAN, (st, stats.iters, msg)
+    assert stats.iters == (1 if pipeline == 0 else 0)  # the persistent kernel counts the loop body it is in; the
+    #                                                    explicit-inverse engine counts an iteration when FTRAN enters it
 
 
 def test_unbounded_direction():
@@ -106,3 +125,59 @@ def test_max_iter_counts_loop_bodies():
                        f["x"], f["B"], f["N"], f["Nb"])
     st, stats, _ = E.primal_solve_with_initial(fp, E.default_opts(max_iter=5))
     assert st == E.MAXITER and stats.iters == 5
+
+
+def _unbounded_after_k(m=400, n=40, seed=3):
+    """a dense LP (all rows Lte, b > 0, x >= 0) whose variable 0 has a very negative cost but a non-positive column
+    EXCEPT that it only becomes the entering variable after a few ordinary pivots (its cost is the least negative):
+    phase-2 arrays from the slack basis; the oracle tells at which iteration the ray is found"""
+    from oracle import ellp_oracle as eo
+    rng = np.random.default_rng(seed)
+    A = rng.uniform(0.1, 1.1, size=(m, n))
+    A[:, 0] = -rng.uniform(0.0, 1.0, size=m)          # nothing ever blocks x0
+    b = A[:, 1:] @ rng.uniform(0.0, 1.0, size=n - 1) + 1.0
+    c = -rng.uniform(1.0, 2.0, size=n)
+    c[0] = -1e-3                                       # Dantzig takes the others first
+    p = eo.Problem()
+    for j in range(n):
+        p.add_var(c[j], ("Lower", 0.0, 0.0))
+    p.add_dense_constraints(A, "Lte", b)
+    p1, err = eo.primal_phase1(p)
+    v = p1.view()
+    st, it, _ = eo.primal_solve_with_initial(v, 100000)
+    assert st == eo.OPTIMAL and abs(v.obj()) < 1e-9
+    p1.store_point(v)
+    return eo, eo.primal_phase2(p1).view()
+
+
+@pytest.mark.parametrize("pipeline", [2, 1])
+def test_unbounded_ray_found_in_the_last_permitted_iteration(pipeline):
+    """max_iter = the iteration in which the reference finds the ray: it runs max_iter FULL loop bodies
+    (primal_simplex_solver.rs:162-202), so the answer is Unbounded, not MaxIter — also on the two-launch pipeline
+    (m >= 384), whose slices leave the last ratio test open."""
+    E = _E()
+    eo, v2 = _unbounded_after_k()
+    ov = v2.copy()
+    st_o, it_o, _ = eo.primal_solve_with_initial(ov, 100000)
+    assert st_o == eo.UNBOUNDED and it_o >= 3
+    for budget, want in ((it_o, E.UNBOUNDED), (it_o - 1, E.MAXITER), (it_o + 5, E.UNBOUNDED)):
+        ob = v2.copy()
+        st_b, it_b, _ = eo.primal_solve_with_initial(ob, budget)
+        assert st_b == want
+        fp = E.FlatProblem(v2.m, v2.n, v2.n_c, v2.A, v2.c, v2.b, v2.kind, v2.lb, v2.ub, v2.x, v2.B, v2.N[:v2.nN], v2.Nb[:v2.nN])
+        st, stats, msg = E.primal_solve_with_initial(fp, E.default_opts(max_iter=budget, pipeline=pipeline))
+        assert st == want, (budget, st, msg)
+        assert stats.iters == it_b
+        np.testing.assert_array_equal(fp.B, ob.B)
+        np.testing.assert_allclose(fp.x, ob.x, rtol=0, atol=1e-9 * (1 + np.abs(ob.x).max()))
+        if want == E.MAXITER:
+            assert abs(stats.obj - float(np.dot(ob.c, ob.x))) <= 1e-9 * (1 + abs(stats.obj))  # the objective of THAT point
+    # resident engine, unlimited budget: a slice that stops right before the ray stays open; read_point completes it
+    fp = E.FlatProblem(v2.m, v2.n, v2.n_c, v2.A, v2.c, v2.b, v2.kind, v2.lb, v2.ub, v2.x, v2.B, v2.N[:v2.nN], v2.Nb[:v2.nN])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, pipeline=pipeline))
+    st, stats, msg = eng.run(it_o)
+    eng.read_point()
+    # either the slice itself completed its last iteration (three launches; or the two-launch pipeline with tiny-pivot
+    # maintenance, which closes every batch) or it was left open and read_point completed it
+    assert st == E.UNBOUNDED or (st == E.MAXITER and eng.closing_status == E.UNBOUNDED), (st, eng.closing_status)
+    eng.close()

@@ -97,17 +97,20 @@ def test_dual_rephase_with_upper_bounds_and_free_variables():
     _case(eo.Problem.from_fixture({"vars": vars_, "constraints": cons}))
 
 
-def test_dual_solver_end_to_end_on_one_resident_engine():
-    """DualSimplexSolver::new(None).solve(problem) through the C++ host mirror: with m > 128 and no dropped
-    variables both phases are slices of ONE resident engine (matrix uploaded once, DualPhase2::from done on
-    the device); the optimum must be HiGHS's"""
+@pytest.mark.parametrize("engine", [{"pipeline": 1}, {}], ids=["explicit-inverse", "default"])
+def test_dual_solver_end_to_end_on_one_resident_engine(engine):
+    """DualSimplexSolver::new(None).solve(problem) through the C++ host mirror.  On an engine of the explicit-inverse
+    kind (m > 512 by default; asked for here) with no dropped variables both phases are slices of ONE resident engine
+    (matrix uploaded once, DualPhase2::from done on the device from a freshly rebuilt inverse).  With default options
+    this size runs the LU-per-iteration kernel, which keeps no inverse: the hand-off is then done on the host, as the
+    reference does it (DualPhase2::point_on_host).  Either way the optimum must be HiGHS's"""
     from scipy.optimize import linprog
     from ellp_amd import DualSimplexSolver, Problem
     m, n = 150, 300
     A, b, c = eo.synth_dense_lp(20260301, m, n)
     fx = {"vars": [[float(c[j]), ["Lower", 0.0, 0.0]] for j in range(n)],
           "constraints": [[[[j, float(A[i, j])] for j in range(n)], "Lte", float(b[i])] for i in range(m)]}
-    r = DualSimplexSolver.new(None).solve(Problem.from_fixture(fx))
+    r = DualSimplexSolver.new(None, **engine).solve(Problem.from_fixture(fx))
     assert r.kind == "optimal"
     h = linprog(c, A_ub=A, b_ub=b, bounds=(0, None), method="highs")
     assert abs(r.solution.obj() - h.fun) < 1e-8 * (1 + abs(h.fun))

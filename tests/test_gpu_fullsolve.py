@@ -1,0 +1,72 @@
+"""Whole solves at BASELINE.json's full sizes through the user API, checked the way the reference's own tests check
+a solve (assert_optimal!: status, objective AND optimal point, tests/problems/mod.rs:9-35) — against an INDEPENDENT
+optimum: SciPy-HiGHS' vertex of the same LP, committed as a small fixture keyed by (generator, seed, m, n)
+(tests/golden/synth_optimum_*.json, made by tools/highs_fixture.py: the support of x and its values).
+
+Tolerances (the stated f64 tolerances of this repository, README.md): objective relative 1e-9, x absolute 1e-8
+(the reference's own are 1e-8 absolute, relative 1e-6: mod.rs:6-7).
+
+config 3 (2000 x 5000, primal): ~6.6e5 pivots, ~30 s of GPU — runs in the routine suite.
+config 5 (4000 x 40000, primal): ~1e6+ pivots, minutes — marked slow: run it with ELLP_SLOW=1; the result of
+the run made for this repository is committed under profiles/."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _fixture(seed, m, n):
+    path = os.path.join(GOLDEN, f"synth_optimum_{seed}_{m}x{n}.json")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} is not committed (tools/highs_fixture.py {m} {n} {seed} makes it)")
+    with open(path) as f:
+        fx = json.load(f)
+    assert (fx["seed"], fx["m"], fx["n"]) == (seed, m, n)
+    x = np.zeros(n)
+    x[np.asarray(fx["support"], dtype=np.int64)] = np.asarray(fx["values"])
+    return fx, x
+
+
+def _solve(seed, m, n, tag):
+    from ellp_amd import Bound, ConstraintOp, PrimalSimplexSolver, Problem, synth
+    fx, x_ref = _fixture(seed, m, n)
+    A, b, c = synth.dense_lp(seed, m, n)
+    p = Problem()
+    ids = [p.add_var(float(c[j]), Bound.Lower(0.0)) for j in range(n)]
+    for i in range(m):
+        p.add_constraint(list(zip(ids, A[i].tolist())), ConstraintOp.Lte, float(b[i]))
+    t0 = time.perf_counter()
+    res = PrimalSimplexSolver.new(None).solve(p)
+    dt = time.perf_counter() - t0
+    assert res.kind == "optimal"
+    obj = res.solution.obj()
+    x = np.asarray(res.solution.x())[:n]
+    rec = {"config": tag, "seed": seed, "m": m, "n": n, "status": res.kind, "objective": obj,
+           "fixture_objective": fx["objective"], "rel_diff_objective": abs(obj - fx["objective"]) / abs(fx["objective"]),
+           "max_abs_diff_x": float(np.abs(x - x_ref).max()), "iterations_phase1_phase2": list(res.iters),
+           "solve_s": round(dt, 2), "pivots_per_s_incl_setup": round(sum(res.iters) / dt, 1)}
+    out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"full_solve_{tag}.json"), "w") as f:
+        json.dump(rec, f)
+    print(json.dumps(rec))
+    # assert_optimal!: objective and point
+    assert abs(obj - fx["objective"]) <= 1e-9 * abs(fx["objective"]), rec
+    assert np.abs(x - x_ref).max() <= 1e-8, rec
+    assert np.all(A @ x <= b + 1e-8) and x.min() >= -1e-9
+    return rec
+
+
+def test_c3_full_solve_matches_committed_optimum():
+    _solve(20260301, 2000, 5000, "c3")
+
+
+@pytest.mark.slow
+def test_c5_full_solve_matches_committed_optimum():
+    _solve(20260305, 4000, 40000, "c5")

@@ -60,7 +60,7 @@ def two_phases(fx, which, max_iter=5000):
         return 0
     v1 = p1.view()
     if v1.m == 0 or (which == "primal" and v1.nN == 0) or v1.m > 128:
-        return 0
+        return 0  # never reaches the device (callers that test ONE fixture skip; campaigns count what ran)
     r = both(v1, which, max_iter)
     assert_identical((which, 1), *r, which)
     ov = r[0]
@@ -89,7 +89,8 @@ def two_phases(fx, which, max_iter=5000):
 @pytest.mark.parametrize("which", ["primal", "dual"])
 @pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
 def test_known_answers_bit_for_bit(fx, which):
-    two_phases(fx, which)
+    if two_phases(fx, which) == 0:
+        pytest.skip("infeasible at setup, m == 0 or no nonbasic column: the seam never sends this fixture to the device")
 
 
 @pytest.mark.parametrize("which", ["primal", "dual"])
