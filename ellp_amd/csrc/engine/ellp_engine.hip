@@ -2748,6 +2748,7 @@ struct ellp_engine {
     // unit columns (PriceArgs::vs_row): per VARIABLE, made once at creation; null = the pricing kernels stream everything
     int32_t *vs_row = nullptr;
     double *vs_val = nullptr;
+    uint8_t *pos_hint = nullptr;
     int64_t unit_columns = 0;  // how many variables have one (diagnostics)
     // 128 < m <= 1024: the same loop with its factors in global memory (ellp_mid.inc); `small` is set as well, so
     // that everything that asks "is there an explicit inverse" keeps working unchanged
@@ -3286,7 +3287,7 @@ void launch_price2(ellp_engine *e, int use_pend) {
     a.p.A_N = e->A_N; a.p.W0 = e->W; a.p.W1 = e->W2; a.p.u = nullptr; a.p.c_N = e->c_N; a.p.Nb = e->Nb;
     a.p.N_index = e->N_index; a.p.dd = nullptr; a.p.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.p.st = e->st;
     a.p.ld = e->ld; a.p.nN = e->nN; a.p.cpb = e->cpb; a.p.block0 = e->rank * e->nbs; a.p.eps = e->eps;
-    a.p.vs_row = e->vs_row; a.p.vs_val = e->vs_val;
+    a.p.vs_row = e->vs_row; a.p.vs_val = e->vs_val; a.pos_hint = e->pos_hint;
     a.u0 = e->u; a.u1 = e->u + e->ld; a.W0 = e->W; a.W1 = e->W2;
     a.d = e->d; a.lam = e->lam; a.bmin = e->bmin; a.bsec = e->bmin + e->m; a.bidx = e->bidx; a.binfo = e->binfo; a.dpos = e->dpos;
     a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
@@ -4027,8 +4028,10 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the primal
     // pricing kernels consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
     if (kind == ELLP_ENGINE_PRIMAL && n_N > 0 && !(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr) {
-        if (dmalloc(e, &e->vs_row, (size_t)n_c) == hipSuccess && dmalloc(e, &e->vs_val, (size_t)n_c) == hipSuccess) {
+        if (dmalloc(e, &e->vs_row, (size_t)n_c) == hipSuccess && dmalloc(e, &e->vs_val, (size_t)n_c) == hipSuccess &&
+            dmalloc(e, &e->pos_hint, (size_t)n_N + 64) == hipSuccess) {
             ECHK(hipMemsetAsync(e->vs_row, 0xff, sizeof(int32_t) * (size_t)n_c, e->stream));
+            ECHK(hipMemsetAsync(e->pos_hint, 0, (size_t)n_N + 64, e->stream));
             hipLaunchKernelGGL(k_scan_singletons, dim3((unsigned)((n_N + 3) / 4)), dim3(256), 0, e->stream, e->A_N, e->ld, m, n_N,
                                e->N_index, e->vs_row, e->vs_val);
             hipLaunchKernelGGL(k_scan_singletons, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, e->stream, e->A_B, e->ld, m, m,
