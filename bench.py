@@ -385,7 +385,11 @@ def roofline_of(meas, m, n, solver, world):
             "traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc passes of an earlier run of this "
                                                    "command, not measured in this run)") if src else None,
             "frac_of_measured_achievable": round(ach / 6290.0, 4),
-            "note": "peak = the 8 TB/s spec; /opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s as achievable by a pure "
+            "note": "achieved = ALGORITHMIC bytes of the pass (SURVEY.md §8d: 8 m |N|, every nonbasic column once) / its "
+                    "duration.  The kernel streams fewer: unit columns (slacks, artificials: a third of config 3's nonbasic "
+                    "columns) are priced from their single entry, so `traffic` (PMC) is BELOW bytes_per_launch and `achieved` can "
+                    "exceed what HBM delivered; ellp_opts.flags = 1 streams everything (tools/unit_columns_ab.py has both).  "
+                    "peak = the 8 TB/s spec; /opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s as achievable by a pure "
                     "streaming read.  The primal kernel's duration includes the ratio-test fold of the previous iteration in "
                     "its prologue (two-launch pipeline), about 2.5 us before the first column is read.",
             "bytes_per_launch": meas["price_bytes"], "avg_us": round(t_us, 3),
