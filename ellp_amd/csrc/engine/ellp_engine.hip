@@ -319,6 +319,7 @@ struct PriceArgs {
     const int32_t *dp_lrow;
     const double *dp_ldelta, *dp_lside, *dp_d;
     int dp_nrb;
+    int dp_maxviol;         // ELLP_FLAG_DUAL_MAX_VIOLATION: the leaving row of largest violation instead of the first violated one
     double *dp_A_N, *dp_A_B, *dp_c_B, *dp_c_N, *dp_x, *dp_dd;
     int64_t *dp_B_index, *dp_N_index;
     uint8_t *dp_Nb;
@@ -335,12 +336,12 @@ struct DualLeave {
     int side;
 };
 __device__ __forceinline__ DualLeave dual_first_violation(const int32_t *lrow, const double *ldelta, const double *lside, int nrb,
-                                                          int tid, long long *s_tmp) {
-    __shared__ double s_ld[4];
+                                                          int tid, long long *s_tmp, int maxviol = 0) {
+    __shared__ double s_ld[4], s_ad[4];
     __shared__ int s_lr[4], s_ls[4];
     const int lane = tid & 63, wave = tid >> 6;
     int bb = 0x7fffffff, brow = -1, bside = 0;
-    double bdelta = 0.0;
+    double bdelta = 0.0, bad = -1.0;  // maxviol (ELLP_FLAG_DUAL_MAX_VIOLATION): the record of largest |delta|, first of equals
     for (int b0 = 0; b0 < nrb; b0 += 1024) {  // four records per thread in flight
         int v[4];
         double dl[4], sd[4];
@@ -355,28 +356,43 @@ __device__ __forceinline__ DualLeave dual_first_violation(const int32_t *lrow, c
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int b = b0 + tid + 256 * u;
-            if (b < nrb && v[u] >= 0 && b < bb) {
+            if (!(b < nrb && v[u] >= 0)) continue;
+            double ad = fabs(dl[u]);
+            if (ad != ad) ad = INFINITY;
+            const bool take = maxviol ? (ad > bad || (ad == bad && b < bb)) : (b < bb);
+            if (take) {
                 bb = b;
                 brow = v[u];
                 bdelta = dl[u];
                 bside = (int)sd[u];
+                bad = ad;
             }
         }
     }
-    const int wb = wave_allmin_dpp(bb);
-    if (bb == wb && wb != 0x7fffffff) {  // one lane per wave (the blocks a wave's lanes hold are distinct)
+    const double wad = maxviol ? wave_allmax_dpp(bad) : 0.0;
+    const int wb = wave_allmin_dpp((!maxviol || bad == wad) ? bb : 0x7fffffff);
+    if (bb == wb && wb != 0x7fffffff && (!maxviol || bad == wad)) {  // one lane per wave (the blocks a wave's lanes hold are distinct)
         s_lr[wave] = brow;
         s_ld[wave] = bdelta;
         s_ls[wave] = bside;
     }
-    if (lane == 0) s_tmp[wave] = wb;
+    if (lane == 0) {
+        s_tmp[wave] = wb;
+        s_ad[wave] = wad;
+    }
     lds_barrier();
     int best = (int)s_tmp[0], bw = 0;
-    for (int w = 1; w < 4; ++w)
-        if ((int)s_tmp[w] < best) {
-            best = (int)s_tmp[w];
+    double bestad = s_ad[0];
+    for (int w = 1; w < 4; ++w) {
+        const int cb = (int)s_tmp[w];
+        const bool take = maxviol ? (cb != 0x7fffffff && (best == 0x7fffffff || s_ad[w] > bestad || (s_ad[w] == bestad && cb < best)))
+                                  : (cb < best);
+        if (take) {
+            best = cb;
+            bestad = s_ad[w];
             bw = w;
         }
+    }
     DualLeave o;
     if (best == 0x7fffffff) {
         o.lr = -1;
@@ -454,7 +470,7 @@ __device__ __forceinline__ void dual_price_prologue(const PriceArgs &a, DevState
         *cur_out = st_cur;
         return;
     }
-    const DualLeave lv = dual_first_violation(a.dp_lrow, a.dp_ldelta, a.dp_lside, a.dp_nrb, tid, s_tmp);
+    const DualLeave lv = dual_first_violation(a.dp_lrow, a.dp_ldelta, a.dp_lside, a.dp_nrb, tid, s_tmp, a.dp_maxviol);
     const long long lr = lv.lr;
     const double ldelta = lv.delta;
     const int lside = lv.side;
@@ -1467,29 +1483,55 @@ __device__ __forceinline__ bool dual_violation(const int64_t *B_index, const dou
     }
     return false;
 }
-// block-wide (256 threads) min-position search; commits lr/ldelta/lside (lr = -1: none)
+// block-wide (256 threads) search for the leaving row; commits lr/ldelta/lside (lr = -1: none).  The reference takes the
+// FIRST violated basic position (dual…:200-236); maxviol (ELLP_FLAG_DUAL_MAX_VIOLATION, an extension): the one with the
+// largest violation, the first of equals.
 __device__ __forceinline__ void find_leaving(const int64_t *B_index, const double *x, const uint8_t *kind,
                                              const double *lb, const double *ub, double eps, int64_t m, int tid,
-                                             long long *s_tmp /*[4]*/, DevState *st) {
+                                             long long *s_tmp /*[4]*/, DevState *st, int maxviol = 0) {
+    __shared__ double s_fad[4];
     const int lane = tid & 63, wave = tid >> 6;
     long long best = INT64_MAX;
+    double bad = -1.0;
     double dl;
     int sd;
     for (int64_t i = tid; i < m; i += 256) {
         if (dual_violation(B_index, x, kind, lb, ub, eps, i, &dl, &sd)) {
-            best = i;
-            break;  // increasing i per thread: the first hit is this thread's minimum
+            if (!maxviol) {
+                best = i;
+                break;  // increasing i per thread: the first hit is this thread's minimum
+            }
+            double ad = fabs(dl);
+            if (ad != ad) ad = INFINITY;
+            if (ad > bad) {
+                bad = ad;
+                best = i;
+            }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const long long ob = __shfl_xor(best, o);
-        best = ob < best ? ob : best;
+        const double oa = __shfl_xor(bad, o);
+        const bool take = maxviol ? (oa > bad || (oa == bad && ob < best)) : (ob < best);
+        if (take) {
+            best = ob;
+            bad = oa;
+        }
     }
-    if (lane == 0) s_tmp[wave] = best;
+    if (lane == 0) {
+        s_tmp[wave] = best;
+        s_fad[wave] = bad;
+    }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w) best = s_tmp[w] < best ? s_tmp[w] : best;
+        for (int w = 1; w < 4; ++w) {
+            const bool take = maxviol ? (s_fad[w] > bad || (s_fad[w] == bad && s_tmp[w] < best)) : (s_tmp[w] < best);
+            if (take) {
+                best = s_tmp[w];
+                bad = s_fad[w];
+            }
+        }
         if (best == INT64_MAX) {
             st->lr = -1;
         } else {
@@ -1534,6 +1576,7 @@ struct Update2Args {
     const double *aq_cur;   // column-sharded engines: the entering column (A_N holds only positions [own0, own1))
     int64_t own0, own1;
     int count_iter;         // 0: closing kernel of the two-launch pipeline (k_ftran_eta has counted the iteration)
+    int maxviol;            // dual: ELLP_FLAG_DUAL_MAX_VIOLATION (find_leaving)
     Trace trace;
 };
 
@@ -1922,7 +1965,7 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             if (d_r != d_r || theta_p != theta_p) st->status = ELLP_ERR_NAN;
         }
         __syncthreads();
-        find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, m, tid, s_tmp, st);
+        find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, m, tid, s_tmp, st, a.maxviol);
         if (tid == 0 && tiny_pivot && st->status == ST_RUNNING) st->tiny = 1;
     }
     STAMP(2, 4);
@@ -1936,11 +1979,12 @@ struct DLeaveArgs {
     DevState *st;
     int64_t m;
     double eps;
+    int maxviol;
 };
 __global__ __launch_bounds__(256) void k_dleave(DLeaveArgs a) {
     __shared__ long long s_tmp[4];
     if (a.st->status != ST_RUNNING) return;
-    find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, a.m, threadIdx.x, s_tmp, a.st);
+    find_leaving(a.B_index, a.x, a.kind, a.lb, a.ub, a.eps, a.m, threadIdx.x, s_tmp, a.st, a.maxviol);
 }
 
 // ------------------------------------------------------------------ BTRAN  u = B^-T c_B  (primal…:184-187)
@@ -2749,6 +2793,7 @@ struct ellp_engine {
     int32_t *vs_row = nullptr;
     double *vs_val = nullptr;
     uint8_t *pos_hint = nullptr;
+    int dual_maxviol = 0;  // ELLP_FLAG_DUAL_MAX_VIOLATION
     int64_t unit_columns = 0;  // how many variables have one (diagnostics)
     // 128 < m <= 1024: the same loop with its factors in global memory (ellp_mid.inc); `small` is set as well, so
     // that everything that asks "is there an explicit inverse" keeps working unchanged
@@ -2948,6 +2993,7 @@ void launch_price(ellp_engine *e) {
         a.dp_seq = e->dual_seq;
         a.dp_lrow = e->binfo; a.dp_ldelta = e->bmin; a.dp_lside = e->bmin + e->m; a.dp_d = e->d;
         a.dp_nrb = (int)((e->m + UPD_ROWS - 1) / UPD_ROWS);
+        a.dp_maxviol = e->dual_maxviol;
         a.dp_A_N = e->A_N; a.dp_A_B = e->A_B; a.dp_c_B = e->c_B; a.dp_c_N = e->c_N; a.dp_x = e->x; a.dp_dd = e->dd;
         a.dp_B_index = e->B_index; a.dp_N_index = e->N_index; a.dp_Nb = e->Nb;
         a.dp_trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
@@ -3009,6 +3055,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.ill_tol = e->ill_tol;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.count_iter = (MODE == 0 && e->lagged) ? 0 : 1;
+    a.maxviol = e->dual_maxviol;
     a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
@@ -3415,7 +3462,7 @@ void launch_dual_close(ellp_engine *e) {
     Prof p(e, ELLP_K_DUPDATE);
     DualCloseArgs c{e->d, e->A_N, e->A_B, e->c_B, e->c_N, e->x, e->dd, e->B_index, e->N_index, e->Nb, e->binfo, e->bmin,
                     e->bmin + e->m, (int)((e->m + UPD_ROWS - 1) / UPD_ROWS), e->st, e->m, e->ld, e->ill_tol,
-                    Trace{e->trace_obj, e->trace_it, e->trace_len}};
+                    Trace{e->trace_obj, e->trace_it, e->trace_len}, e->dual_maxviol};
     hipLaunchKernelGGL(k_dual_close, dim3(1), dim3(256), 0, e->stream, c);
     e->dual_open = false;
 }
@@ -3429,6 +3476,7 @@ void launch_dual_fu(ellp_engine *e) {
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.lrow = e->binfo; a.ldelta = e->bmin; a.lside = e->bmin + e->m;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.eps = e->eps;
     a.seq = e->dual_seq;
+    a.maxviol = e->dual_maxviol;
     const dim3 g((unsigned)((e->m + UPD_ROWS - 1) / UPD_ROWS) + DFU_BOOK), b(256);
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
     if (nr <= 1) hipLaunchKernelGGL((k_dual_fu<1>), g, b, 0, e->stream, a);
@@ -3473,7 +3521,7 @@ void launch_dual_iteration(ellp_engine *e) {
 
 void launch_dleave(ellp_engine *e) {
     Prof p(e, ELLP_K_DLEAVE);
-    DLeaveArgs a{e->x, e->lb, e->ub, e->kindv, e->B_index, e->st, e->m, e->eps};
+    DLeaveArgs a{e->x, e->lb, e->ub, e->kindv, e->B_index, e->st, e->m, e->eps, e->dual_maxviol};
     hipLaunchKernelGGL(k_dleave, dim3(1), dim3(256), 0, e->stream, a);
 }
 
@@ -4025,6 +4073,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
             }
         }
     }
+    e->dual_maxviol = (kind == ELLP_ENGINE_DUAL && (e->opts.flags & ELLP_FLAG_DUAL_MAX_VIOLATION)) ? 1 : 0;
     // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the primal
     // pricing kernels consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
     if (kind == ELLP_ENGINE_PRIMAL && n_N > 0 && !(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr) {
@@ -4214,6 +4263,7 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
             a.eps = e->eps;
             a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
             a.stamps = e->small_stamps;
+            a.maxviol = e->dual_maxviol;
             // the row-major copy of A_N the pricing pass reads: made afresh at every launch (anything may have
             // touched A_N in between: a hand-off, a sharding call, the other engine)
             hipLaunchKernelGGL(k_mid_transpose, dim3((unsigned)((e->m + 31) / 32), (unsigned)((e->nN + 31) / 32)), dim3(256), 0,
@@ -4232,6 +4282,7 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
             a.eps = e->eps;
             a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
             a.stamps = e->small_stamps;
+            a.maxviol = e->dual_maxviol;
             void *kargs[] = {&a};
             HIPCHK(hipLaunchKernel(small_kernel(e->kind, e->small_nt), dim3(1), dim3((unsigned)e->small_nt), kargs,
                                    e->small_lds, e->stream));

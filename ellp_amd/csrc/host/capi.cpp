@@ -95,6 +95,7 @@ int ellp_solve(const ellp_problem *p, int solver, uint64_t max_iter, const ellp_
         eo.poll_interval = opts->poll_interval;
         eo.pipeline = opts->pipeline;
         eo.partial_segments = opts->partial_segments;
+        eo.flags = opts->flags;
     }
     const std::optional<std::uint64_t> mi =
         max_iter == ELLP_MAX_ITER_NONE ? std::nullopt : std::optional<std::uint64_t>(max_iter);

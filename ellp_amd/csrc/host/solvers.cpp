@@ -57,6 +57,7 @@ ellp_opts make_opts(std::uint64_t max_iter, const EngineOptions &e) {
     o.poll_interval = e.poll_interval;
     o.pipeline = e.pipeline;
     o.partial_segments = e.partial_segments;
+    o.flags = e.flags;
     return o;
 }
 

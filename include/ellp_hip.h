@@ -59,6 +59,7 @@ enum { ELLP_NB_LOWER = 0, ELLP_NB_UPPER = 1, ELLP_NB_FREE = 2 };
 
 #define ELLP_MAX_ITER_NONE UINT64_MAX /* PrimalSimplexSolver::new(None), primal…:26-30 */
 #define ELLP_FLAG_DENSE_PRICING 1      /* ellp_opts.flags */
+#define ELLP_FLAG_DUAL_MAX_VIOLATION 2 /* ellp_opts.flags */
 
 typedef struct ellp_opts {
     uint64_t max_iter;       /* self.max_iter (primal…:16, dual…:17); default 1000 (:21) */
@@ -86,7 +87,12 @@ typedef struct ellp_opts {
                                  engines on one GPU, three-launch pipeline.  0 or 1: every column every iteration */
     int32_t flags;           /* bit 0 (ELLP_FLAG_DENSE_PRICING): stream every nonbasic column in the primal pricing pass,
                                 also the unit columns (slacks, artificials), whose dot product the kernels otherwise
-                                form from their single entry — same numbers, measured both ways by bench.py */
+                                form from their single entry — same numbers, measured both ways by bench.py
+                                bit 1 (ELLP_FLAG_DUAL_MAX_VIOLATION), an EXTENSION, dual engines: the leaving
+                                row is the basic position with the LARGEST bound violation (first of equals) instead of the
+                                first violated one (dual_simplex_solver.rs:200-236).  Not the reference's rule — restated in
+                                the oracle (eo_set_dual_rule(2)) and checked against it; 24 x fewer iterations on the 200 x 500
+                                LP of SURVEY.md §8d, and what makes a dual solve at config 4's size finish at all */
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */

@@ -79,6 +79,18 @@ void eo_set_dense_lu(int on) { g_dense_lu = on; }
 static int g_partial_segments = 0;
 void eo_set_partial_segments(int P) { g_partial_segments = P > 1 ? P : 0; }
 
+/* Dual extensions (NOT the reference's rules, off by default; eo_set_dual_rule):
+ *   bit 0  bound-flipping ("long-step") ratio test: the dual step goes past the breakpoints of BOXED nonbasic
+ *          variables — each is moved to its other bound instead of entering — for as long as the dual objective
+ *          keeps growing, i.e. while the infeasibility |delta| of the leaving row minus the sum of
+ *          |alpha_j| (ub_j - lb_j) over the passed breakpoints stays positive; the breakpoint at which it
+ *          would turn non-positive (or the first one of a variable that has no other bound) enters.
+ *          Breakpoints are taken in the order (ratio, position).
+ *   bit 1  the leaving row is the one with the LARGEST bound violation (first of equals) instead of the first
+ *          violated one. */
+static int g_dual_rule = 0;
+void eo_set_dual_rule(int bits) { g_dual_rule = bits; }
+
 static int g_setup_threads = 1;
 void eo_set_setup_threads(int n) { g_setup_threads = n > 1 ? n : 1; }
 
@@ -1628,6 +1640,9 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
     double *rho = (double *)xmalloc(sizeof(double) * (size_t)m);
     double *alpha = (double *)xmalloc(sizeof(double) * (size_t)nN);
     double *alpha_q = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *flipcol = (double *)xmalloc(sizeof(double) * (size_t)m);
+    double *bf_ratio = (double *)xmalloc(sizeof(double) * (size_t)(nN + 1));
+    int64_t *bf_pos = (int64_t *)xmalloc(sizeof(int64_t) * (size_t)(nN + 1));
     lu_t f;
     f.lu = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
     f.nr = f.nc = m;
@@ -1648,21 +1663,29 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
         int64_t r = -1;
         double delta = 0.0;
         int side = EO_NB_LOWER;
-        for (int64_t i = 0; i < m && r < 0; ++i) {
+        for (int64_t i = 0; i < m && (r < 0 || (g_dual_rule & 2)); ++i) {
             const int64_t bi = B[i];
             double xi = x[bi];
+            int64_t ri = -1;
+            double di = 0.0;
+            int si = EO_NB_LOWER;
             switch (kind[bi]) {
             case EO_LOWER:
-                if (xi < lb[bi] - EPS) { r = i; delta = xi - lb[bi]; side = EO_NB_LOWER; }
+                if (xi < lb[bi] - EPS) { ri = i; di = xi - lb[bi]; si = EO_NB_LOWER; }
                 break;
             case EO_UPPER:
-                if (xi > ub[bi] + EPS) { r = i; delta = xi - ub[bi]; side = EO_NB_UPPER; }
+                if (xi > ub[bi] + EPS) { ri = i; di = xi - ub[bi]; si = EO_NB_UPPER; }
                 break;
             case EO_TWOSIDED:
-                if (xi > ub[bi] + EPS) { r = i; delta = xi - ub[bi]; side = EO_NB_UPPER; }
-                else if (xi < lb[bi] - EPS) { r = i; delta = xi - lb[bi]; side = EO_NB_LOWER; }
+                if (xi > ub[bi] + EPS) { ri = i; di = xi - ub[bi]; si = EO_NB_UPPER; }
+                else if (xi < lb[bi] - EPS) { ri = i; di = xi - lb[bi]; si = EO_NB_LOWER; }
                 break;
             default: break; /* Free, Fixed never leave (quirk Q3) */
+            }
+            if (ri >= 0 && (r < 0 || fabs(di) > fabs(delta))) { /* extension bit 1: the largest violation, first of equals */
+                r = ri;
+                delta = di;
+                side = si;
             }
         }
         /* :241 LU before the optimality test (quirk Q4) */
@@ -1723,12 +1746,76 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
             status = EO_INFEASIBLE;
             break;
         }
+        int64_t nflip = 0;
+        if (g_dual_rule & 1) {
+            /* extension bit 0: walk the breakpoints in (ratio, position) order */
+            int64_t nc = 0;
+            for (int64_t j = 0; j < nN; ++j) {
+                int keep;
+                if (Nb[j] == EO_NB_LOWER) keep = alpha[j] > EPS;
+                else if (Nb[j] == EO_NB_UPPER) keep = alpha[j] < -EPS;
+                else keep = 1;
+                if (keep) bf_pos[nc++] = j;
+            }
+            for (int64_t k = 0; k < nc; ++k) bf_ratio[k] = d[N[bf_pos[k]]] / alpha[bf_pos[k]];
+            /* insertion into sorted order by (ratio, position) as far as needed: selection, one breakpoint at a time */
+            double slope = fabs(delta);
+            int64_t taken = 0;
+            for (;;) {
+                int64_t best = -1;
+                for (int64_t k = taken; k < nc; ++k)
+                    if (best < 0 || bf_ratio[k] < bf_ratio[best] || (bf_ratio[k] == bf_ratio[best] && bf_pos[k] < bf_pos[best])) best = k;
+                /* move it to slot `taken` */
+                const int64_t pj = bf_pos[best];
+                const double pr = bf_ratio[best];
+                bf_pos[best] = bf_pos[taken];
+                bf_ratio[best] = bf_ratio[taken];
+                bf_pos[taken] = pj;
+                bf_ratio[taken] = pr;
+                const int64_t vj = N[pj];
+                const int boxed = kind[vj] == EO_TWOSIDED;
+                const double drop = boxed ? fabs(alpha[pj]) * (ub[vj] - lb[vj]) : INFINITY;
+                if (!boxed || !(slope - drop > 0.0) || taken + 1 == nc) { /* this one enters */
+                    q = pj;
+                    theta_dual = pr;
+                    break;
+                }
+                slope -= drop;
+                taken += 1;
+            }
+            nflip = taken;
+        }
         if (delta < 0.0) { /* :286-289 */
             for (int64_t j = 0; j < nN; ++j) alpha[j] = -alpha[j];
             theta_dual = -theta_dual;
         }
         const int64_t leaving_var = B[r];
         const int64_t entering_var = N[q];
+        if (nflip > 0) {
+            /* the passed variables change bound: x_N moves, x_B follows by B^-1 (sum of a_j dx_j); the dual objective
+             * gains what the passed stretches contribute (recomputed below from scratch would be the same) */
+            memset(flipcol, 0, sizeof(double) * (size_t)m);
+            for (int64_t k = 0; k < nflip; ++k) {
+                const int64_t pj = bf_pos[k];
+                const int64_t vj = N[pj];
+                const double dx = (Nb[pj] == EO_NB_LOWER) ? (ub[vj] - lb[vj]) : (lb[vj] - ub[vj]);
+                const double *cj = A_N + pj * m;
+                for (int64_t i = 0; i < m; ++i) flipcol[i] += cj[i] * dx;
+                x[vj] = (Nb[pj] == EO_NB_LOWER) ? ub[vj] : lb[vj];
+                Nb[pj] = (Nb[pj] == EO_NB_LOWER) ? EO_NB_UPPER : EO_NB_LOWER;
+            }
+            if (!lu_solve(&f, flipcol)) {
+                set_err(err, errlen, "unwrap() on None in the bound-flip FTRAN");
+                status = EO_ERR_PANIC;
+                break;
+            }
+            for (int64_t i = 0; i < m; ++i) x[B[i]] -= flipcol[i];
+            /* the leaving row's violation after the flips */
+            {
+                const int64_t bi = B[r];
+                delta = (side == EO_NB_UPPER) ? x[bi] - ub[bi] : x[bi] - lb[bi];
+            }
+        }
         memcpy(alpha_q, A + entering_var * m, sizeof(double) * (size_t)m);
         if (!lu_solve(&f, alpha_q)) { /* :294 */
             set_err(err, errlen, "unwrap() on None in dual FTRAN");
@@ -1757,7 +1844,7 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
     }
     if (iters_out) *iters_out = entered;
     lu_free(&f);
-    free(A_B); free(A_N); free(rho); free(alpha); free(alpha_q);
+    free(A_B); free(A_N); free(rho); free(alpha); free(alpha_q); free(flipcol); free(bf_ratio); free(bf_pos);
     return status;
 }
 

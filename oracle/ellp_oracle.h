@@ -157,6 +157,9 @@ void eo_set_trace(eo_trace_fn fn, void *user);
 void eo_set_dense_lu(int on);
 /* threads for the once-per-solve setup factorizations (bitwise the one-thread results); default 1 */
 void eo_set_setup_threads(int n);
+/* dual extensions for eo_dual_solve_with_initial (see ellp_oracle.c): bit 0 bound-flipping ratio test, bit 1 leaving
+ * row of largest violation; 0 = the reference's rules */
+void eo_set_dual_rule(int bits);
 /* partial pricing for eo_primal_solve_with_initial (an extension, see ellp_oracle.c); P <= 1: off */
 void eo_set_partial_segments(int P);
 
