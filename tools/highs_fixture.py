@@ -23,19 +23,23 @@ assert r.status == 0, r.message
 x = np.asarray(r.x)
 # polish the vertex: the basis is (support of x) + (slacks of the rows that are not tight); solve it in double
 slack = b - A @ x
-sup = np.flatnonzero(x > 1e-9)
-tight = np.flatnonzero(slack < 1e-7)
+sup = np.flatnonzero(x > 1e-7)
+tight = np.argsort(slack)[:len(sup)]  # a nondegenerate vertex has as many tight rows as positive variables (HiGHS leaves them
+#                                       tight to its feasibility tolerance only: 5.6e-6 at 4000 x 40000)
 info = {"generator": "splitmix64 dense LP, SURVEY.md 8d (ellp_amd/synth.py::dense_lp)", "seed": seed, "m": m, "n": n,
         "solver": "scipy.optimize.linprog(method='highs-ds'), feasibility tolerances 1e-10", "seconds": round(dt, 1)}
-if len(sup) == len(tight):  # a nondegenerate vertex: x_S = A[tight, S]^-1 b[tight]
-    xs = np.linalg.solve(A[np.ix_(tight, sup)], b[tight])
-    x2 = np.zeros(n)
-    x2[sup] = xs
-    info["polished"] = True
-    info["polish_max_change"] = float(np.abs(x2 - x).max())
-    x = x2
-else:
-    info["polished"] = False
+xs = np.linalg.solve(A[np.ix_(tight, sup)], b[tight])  # x_S = A[tight, S]^-1 b[tight] in double precision
+x2 = np.zeros(n)
+x2[sup] = xs
+y = np.zeros(m)
+y[tight] = np.linalg.solve(A[np.ix_(tight, sup)].T, c[sup])
+rc = c - A.T @ y
+# the polished point must be a feasible vertex with nonnegative reduced costs: then it IS the optimum
+assert xs.min() > 0 and (A @ x2 - b).max() < 1e-9 and rc.min() > -1e-9 and y.max() < 1e-9, "not a nondegenerate optimal vertex"
+info["polished"] = True
+info["polish_max_change"] = float(np.abs(x2 - x).max())
+info["dual_check"] = {"min_reduced_cost": float(rc.min()), "max_row_multiplier": float(y.max())}
+x = x2
 info["objective"] = float(c @ x)
 info["highs_objective"] = float(r.fun)
 info["support"] = [int(j) for j in np.flatnonzero(x != 0.0)]
