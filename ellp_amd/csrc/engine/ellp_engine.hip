@@ -126,6 +126,12 @@ struct DevState {
     // ---- fused dual iterations (ellp_dualfu.inc): k_dual_fu number dp_seq has left the swap / scalars / next leaving
     // row of its pivot to be done (~0: nothing is left); dp_applied = the last one the following pricing launch did
     unsigned long long dp_seq, dp_applied;
+    // ---- steepest-edge pricing (ELLP_FLAG_PRIMAL_STEEPEST_EDGE; ellp_se.inc): what k_update2<0> leaves of the pivot it made
+    // for the weight update in the next pricing launch: the entering position, the unsigned pivot element alpha_q[r], the
+    // entering variable's weight, and whether d = -alpha_q (entering at its lower bound)
+    int32_t se_valid, se_neg;
+    int64_t se_q;
+    double se_arq, se_gq;
 #ifdef ELLP_DBG_STAMPS
     long long dbg[3][4][8];  // [kernel][block selector][stamp] wall_clock64 (100 MHz) — dev builds only
 #endif
@@ -1577,6 +1583,8 @@ struct Update2Args {
     int64_t own0, own1;
     int count_iter;         // 0: closing kernel of the two-launch pipeline (k_ftran_eta has counted the iteration)
     int maxviol;            // dual: ELLP_FLAG_DUAL_MAX_VIOLATION (find_leaving)
+    const double *se_gamma; // primal, steepest edge: weights by nonbasic position (null: off)
+    double *se_rho;         // ... the pivot row of the inverse this pivot was decided with, kept for the weight update
     Trace trace;
 };
 
@@ -1825,13 +1833,19 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 const double cf = st->s_rq / alpha_r;
                 const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
                 double2 *u2 = reinterpret_cast<double2 *>(st->usel ? a.u_alt : a.u);
+                double2 *sr = reinterpret_cast<double2 *>(a.se_rho);
                 for (int64_t t = tid; t < (a.ld >> 1); t += 256) {
                     const double2 p = rho2[t];
                     double2 w = u2[t];
                     w.x = fma(cf, p.x, w.x);
                     w.y = fma(cf, p.y, w.y);
                     u2[t] = w;
+                    if (sr) sr[t] = p;
                 }
+            } else if (a.se_rho) {
+                const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
+                double2 *sr = reinterpret_cast<double2 *>(a.se_rho);
+                for (int64_t t = tid; t < (a.ld >> 1); t += 256) sr[t] = rho2[t];
             }
             if (a.aq_cur) {
                 // column-sharded: the owner of position q takes the leaving column (A_B is replicated), every
@@ -1858,6 +1872,16 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
             return;
         }
         // block 0: the point, the basic side of the swap, the counters
+        double se_norm2 = 0.0;
+        if (a.se_gamma && r >= 0) {  // steepest edge: the entering variable's weight taken EXACTLY, 1 + |alpha_q|^2
+            __shared__ double s_n2[4];
+            double acc = 0.0;
+            for (int64_t i = tid; i < m; i += 256) acc = fma(a.d[i], a.d[i], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) s_n2[wave] = acc;
+            __syncthreads();
+            se_norm2 = ((s_n2[0] + s_n2[1]) + s_n2[2]) + s_n2[3];
+        }
         if (lambda > 0.0) {  // primal…:408-417
             for (int64_t i0 = tid; i0 < m; i0 += 4 * 256) {
                 int64_t bi[4];
@@ -1891,10 +1915,18 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                 if (lambda > 0.0) st->obj = st->obj + (at_lower ? lambda * st->s_rq : -(lambda * st->s_rq));
                 trace_put(a.trace, st->iters, st->obj);
                 if (tiny_pivot) st->tiny = 1;
+                if (a.se_gamma) {
+                    st->se_valid = 1;
+                    st->se_neg = at_lower;
+                    st->se_q = q;
+                    st->se_arq = alpha_r;
+                    st->se_gq = 1.0 + se_norm2;
+                }
             }
         } else if (tid == 0) {  // primal…:223-231
             const int nbq = a.Nb[q];
             st->lambda = lambda;
+            if (a.se_gamma) st->se_valid = 0;  // a bound flip leaves the weights alone
             if (nbq == ELLP_NB_LOWER) a.Nb[q] = ELLP_NB_UPPER;
             else if (nbq == ELLP_NB_UPPER) a.Nb[q] = ELLP_NB_LOWER;
             else {
@@ -2688,6 +2720,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
 #include "ellp_rebuild.inc"
 #include "ellp_small.inc"
 #include "ellp_mid.inc"
+#include "ellp_se.inc"
 
 }  // namespace
 
@@ -2794,6 +2827,8 @@ struct ellp_engine {
     double *vs_val = nullptr;
     uint8_t *pos_hint = nullptr;
     int dual_maxviol = 0;  // ELLP_FLAG_DUAL_MAX_VIOLATION
+    bool se = false;       // ELLP_FLAG_PRIMAL_STEEPEST_EDGE (ellp_se.inc): three launches + one transposed GEMV per iteration
+    double *se_gamma = nullptr, *se_rho = nullptr, *se_v = nullptr;
     int64_t unit_columns = 0;  // how many variables have one (diagnostics)
     // 128 < m <= 1024: the same loop with its factors in global memory (ellp_mid.inc); `small` is set as well, so
     // that everything that asks "is there an explicit inverse" keeps working unchanged
@@ -2987,8 +3022,8 @@ void launch_price(ellp_engine *e) {
     a.block0 = e->rank * e->nbs;
     a.eps = e->eps;
     a.pp_on = e->pp_P > 1 ? 1 : 0;
-    a.vs_row = MODE == 0 ? e->vs_row : nullptr;
-    a.vs_val = MODE == 0 ? e->vs_val : nullptr;
+    a.vs_row = (MODE == 0 && !(e->opts.flags & ELLP_FLAG_DENSE_PRICING)) ? e->vs_row : nullptr;
+    a.vs_val = a.vs_row ? e->vs_val : nullptr;
     if (MODE == 1 && e->dual_fold) {
         a.dp_seq = e->dual_seq;
         a.dp_lrow = e->binfo; a.dp_ldelta = e->bmin; a.dp_lside = e->bmin + e->m; a.dp_d = e->d;
@@ -3056,6 +3091,8 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.count_iter = (MODE == 0 && e->lagged) ? 0 : 1;
     a.maxviol = e->dual_maxviol;
+    a.se_gamma = (MODE == 0 && e->se) ? e->se_gamma : nullptr;
+    a.se_rho = (MODE == 0 && e->se) ? e->se_rho : nullptr;
     a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
@@ -3426,6 +3463,16 @@ void launch_flush(ellp_engine *e) {
     e->lag_open = false;
 }
 
+void launch_price_se(ellp_engine *e) {
+    SeArgs a{};
+    a.A_N = e->A_N; a.u = e->u; a.rho = e->se_rho; a.v = e->se_v; a.c_N = e->c_N; a.Nb = e->Nb; a.N_index = e->N_index;
+    a.gamma = e->se_gamma;
+    const bool unit_ok = !(e->opts.flags & ELLP_FLAG_DENSE_PRICING);
+    a.vs_row = unit_ok ? e->vs_row : nullptr; a.vs_val = unit_ok ? e->vs_val : nullptr;
+    a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.st = e->st; a.ld = e->ld; a.nN = e->nN; a.cpb = e->cpb; a.eps = e->eps;
+    hipLaunchKernelGGL(k_price_se, dim3((unsigned)e->nblocks), dim3(256), 0, e->stream, a);
+}
+
 void launch_primal_iteration(ellp_engine *e) {
     if (e->lagged) {
         launch_primal_iteration_lagged(e);
@@ -3440,11 +3487,19 @@ void launch_primal_iteration(ellp_engine *e) {
     }
     {
         Prof p(e, ELLP_K_PRICE);
-        launch_price<0>(e);
+        if (e->se) launch_price_se(e);
+        else launch_price<0>(e);
     }
     {
         Prof p(e, ELLP_K_FTRAN);
         launch_ftran2<0>(e);
+    }
+    if (e->se) {  // v = B^-T d from the inverse this iteration's FTRAN used: the weight update of the NEXT pricing launch
+        Prof p(e, ELLP_K_BTRAN);
+        BtranArgs a{e->W, e->W2, e->d, e->upart, e->se_v, e->se_v, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
+        const int64_t half = e->ld >> 1;
+        hipLaunchKernelGGL(k_btran_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0, e->stream, a);
+        hipLaunchKernelGGL(k_btran_reduce, dim3((unsigned)((e->ld + 255) / 256)), dim3(256), 0, e->stream, a);
     }
     launch_drift_check(e);
     {
@@ -4074,9 +4129,11 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         }
     }
     e->dual_maxviol = (kind == ELLP_ENGINE_DUAL && (e->opts.flags & ELLP_FLAG_DUAL_MAX_VIOLATION)) ? 1 : 0;
+    e->se = kind == ELLP_ENGINE_PRIMAL && (e->opts.flags & ELLP_FLAG_PRIMAL_STEEPEST_EDGE) && n_N > 0 && e->pp_P <= 1;
     // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the primal
     // pricing kernels consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
-    if (kind == ELLP_ENGINE_PRIMAL && n_N > 0 && !(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr) {
+    if (kind == ELLP_ENGINE_PRIMAL && n_N > 0 &&
+        (e->se || (!(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr))) {
         if (dmalloc(e, &e->vs_row, (size_t)n_c) == hipSuccess && dmalloc(e, &e->vs_val, (size_t)n_c) == hipSuccess &&
             dmalloc(e, &e->pos_hint, (size_t)n_N + 64) == hipSuccess) {
             ECHK(hipMemsetAsync(e->vs_row, 0xff, sizeof(int32_t) * (size_t)n_c, e->stream));
@@ -4102,7 +4159,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         int64_t mid_auto = 512;
         if (const char *ev = getenv("ELLP_MID_AUTO_MAX")) mid_auto = atoll(ev);
         const bool fits = e->small_lds > 0 || e->mid_lds > 0;
-        const bool wanted = e->pp_P <= 1 && (pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
+        const bool wanted = e->pp_P <= 1 && !e->se && (pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
                                                          e->opts.profile == 0 && (m <= SMALL_MAX_M || m <= mid_auto)));
         if (pl == 3 && !fits) {
             set_err(errbuf, errlen, "pipeline 3 (one persistent workgroup, LU every iteration) needs m <= %d", MID_MAX_M);
@@ -4150,12 +4207,32 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     // two launches per primal iteration from m = 1024 (ellp_lagged.inc), or on request
     {
         const int pl = e->opts.pipeline;
-        e->lagged = !e->small && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
+        e->lagged = !e->small && !e->se && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
                     (pl == 2 || (pl == 0 && m >= 384));  // partial pricing runs on the three-launch pipeline; tools/pipeline_threshold.py for the size
         e->dual_fused = !e->small && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 384));
         e->dual_fold = e->dual_fused && e->ill_tol <= 0.0 && getenv("ELLP_DUAL_FOLD_OFF") == nullptr;
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
+    }
+    // steepest-edge weights (ellp_se.inc): exact at a signed-permutation basis, 1 otherwise
+    if (e->se) {
+        if (!e->vs_row) {
+            set_err(errbuf, errlen, "no device memory for the steepest-edge tables");
+            ellp_engine_destroy(e);
+            return ELLP_ERR_DEVICE;
+        }
+        int32_t *perm = nullptr;
+        ECHK(dmalloc(e, &e->se_gamma, (size_t)n_N));
+        ECHK(dmalloc(e, &e->se_rho, (size_t)ld));
+        ECHK(dmalloc(e, &e->se_v, (size_t)ld));
+        ECHK(dmalloc(e, &perm, 4));
+        ECHK(hipMemsetAsync(e->se_rho, 0, sizeof(double) * (size_t)ld, e->stream));
+        ECHK(hipMemsetAsync(e->se_v, 0, sizeof(double) * (size_t)ld, e->stream));
+        hipLaunchKernelGGL(k_se_perm, dim3(1), dim3(256), 0, e->stream, e->B_index, m, e->vs_row, e->vs_val, perm);
+        hipLaunchKernelGGL(k_se_init, dim3((unsigned)((n_N + 3) / 4)), dim3(256), 0, e->stream, e->A_N, ld, m, n_N, perm, e->se_gamma);
+        if (e->opts.flags & ELLP_FLAG_DENSE_PRICING) {  // the table was only needed for the permutation test
+            e->pos_hint = nullptr;
+        }
     }
     // initial B^-1 (k_small keeps none: its LU is redone every iteration, with the reference's guard)
     if (e->small) e->w_valid = false;
@@ -4548,6 +4625,11 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
         count = e->nN;
         break;
     case ELLP_TAP_D: src = e->d; count = e->m; break;
+    case 7:  // steepest-edge weights by nonbasic position (diagnostics; valid up to the last pricing launch)
+        if (!e->se) return ELLP_ERR_ARG;
+        src = e->se_gamma;
+        count = e->nN;
+        break;
     case ELLP_TAP_KEY:
         if (e->world != 1) return ELLP_ERR_ARG;
         src = e->X + 2 * e->nbs;
@@ -4864,6 +4946,7 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     ns.fin = 0;
     ns.pe_valid = 0;
     ns.open = 0;
+    ns.se_valid = 0;  // steepest edge: the last pivot's weight update has been applied by the pricing launch that ended the phase
     ns.mv_pending = 0;
     ns.pp_seg = 0;  // partial pricing starts over with the first segment
     ns.pp_empty = 0;

@@ -160,6 +160,8 @@ void eo_set_setup_threads(int n);
 /* dual extensions for eo_dual_solve_with_initial (see ellp_oracle.c): bit 0 bound-flipping ratio test, bit 1 leaving
  * row of largest violation; 0 = the reference's rules */
 void eo_set_dual_rule(int bits);
+/* primal extension for eo_primal_solve_with_initial (see ellp_oracle.c): 1 = steepest-edge pricing; 0 = the reference's rule */
+void eo_set_primal_rule(int rule);
 /* partial pricing for eo_primal_solve_with_initial (an extension, see ellp_oracle.c); P <= 1: off */
 void eo_set_partial_segments(int P);
 

@@ -112,6 +112,7 @@ def lib():
     L.eo_set_setup_threads.argtypes = [C.c_int]
     L.eo_set_partial_segments.argtypes = [C.c_int]
     L.eo_set_dual_rule.argtypes = [C.c_int]
+    L.eo_set_primal_rule.argtypes = [C.c_int]
     L.eo_synth_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
     _lib = L
@@ -392,6 +393,11 @@ def set_dual_rule(bits):
     """dual extensions in dual_solve_with_initial (not the reference's rules; see ellp_oracle.c): bit 0 bound-flipping
     ratio test, bit 1 leaving row of largest violation; 0 restores the reference's rules"""
     lib().eo_set_dual_rule(int(bits))
+
+
+def set_primal_rule(rule):
+    """primal extension in primal_solve_with_initial (not the reference's rule; see ellp_oracle.c): 1 steepest-edge pricing"""
+    lib().eo_set_primal_rule(int(rule))
 
 
 def set_partial_segments(P):

@@ -69,4 +69,43 @@ def test_c3_full_solve_matches_committed_optimum():
 
 @pytest.mark.slow
 def test_c5_full_solve_matches_committed_optimum():
-    _solve(20260305, 4000, 40000, "c5")
+    """config 5 at the seam: phase 1 and phase 2 as two solve_with_initial calls on the arrays the reference's phases hand
+    over (ellp_amd/synth.py builds them directly: 160 M coefficients through the Python Problem API would take longer than
+    the solve), in slices so that progress is visible"""
+    from ellp_amd import _engine as E
+    from ellp_amd import synth
+    seed, m, n = 20260305, 4000, 40000
+    fx, x_ref = _fixture(seed, m, n)
+    flat = synth.primal_phase1_flat(seed, m, n)
+    t0 = time.perf_counter()
+    iters, secs = [], []
+    f = flat
+    for phase in (1, 2):
+        fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"])
+        eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+        st, loop_s = E.MAXITER, 0.0
+        while st == E.MAXITER:
+            st, stats, msg = eng.run(100000)
+            loop_s += stats.t_loop_s
+            print(f"phase {phase}: {int(stats.iters)} iterations, {loop_s:.1f} s, objective {stats.obj:.12g}", flush=True)
+        eng.read_point()
+        eng.close()
+        assert st == E.OPTIMAL, msg
+        iters.append(int(stats.iters))
+        secs.append(loop_s)
+        if phase == 1:
+            assert abs(fp.obj()) < 1e-7
+            f = synth.primal_phase2_from(flat, fp.x, fp.B, fp.N, fp.Nb)
+    obj = fp.obj()
+    x = fp.x[:n]
+    rec = {"config": "c5", "seed": seed, "m": m, "n": n, "status": "optimal", "objective": obj, "fixture_objective": fx["objective"],
+           "rel_diff_objective": abs(obj - fx["objective"]) / abs(fx["objective"]), "max_abs_diff_x": float(np.abs(x - x_ref).max()),
+           "iterations_phase1_phase2": iters, "loop_s_phase1_phase2": [round(v, 2) for v in secs],
+           "pivots_per_s_in_the_loops": round(sum(iters) / sum(secs), 1), "wall_s": round(time.perf_counter() - t0, 1)}
+    out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "full_solve_c5.json"), "w") as fh:
+        json.dump(rec, fh)
+    print(json.dumps(rec))
+    assert abs(obj - fx["objective"]) <= 1e-9 * abs(fx["objective"]), rec
+    assert np.abs(x - x_ref).max() <= 1e-8, rec

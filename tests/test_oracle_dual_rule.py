@@ -49,3 +49,21 @@ def test_iteration_counts_on_the_synthetic_family():
         assert r.status == eo.OPTIMAL and abs(r.obj - (-127.83583703722091)) < 1e-8 * 128
         counts[rule] = sum(r.iters)
     assert counts[0] > 20000 and counts[2] < counts[0] // 10 and counts[3] < counts[2]
+
+
+@pytest.mark.parametrize("fx", KA["problems"] + KA["netlib"], ids=[p["name"] for p in KA["problems"] + KA["netlib"]])
+def test_known_answers_under_steepest_edge_pricing(fx):
+    """the primal extension (eo_set_primal_rule(1), exact steepest-edge weights): same answers as the reference's Dantzig rule"""
+    eo.set_primal_rule(1)
+    try:
+        if "file" in fx:
+            r = eo.solve(eo.Problem.from_fixture(read_mps(os.path.join(GOLDEN, fx["file"]))), "primal", None)
+            assert r.status == eo.OPTIMAL and abs(r.obj / fx["obj"] - 1.0) < 1e-6
+            return
+        r = eo.solve(eo.Problem.from_fixture(fx), "primal", None)
+        if fx["check"] == "optimal":
+            assert r.status == eo.OPTIMAL and abs(r.obj - fx["obj"]) < 1e-8
+        else:
+            check_result(fx, eo.STATUS_NAME.get(r.status, str(r.status)), r.obj, r.x)
+    finally:
+        eo.set_primal_rule(0)
