@@ -93,7 +93,7 @@ void eo_set_dual_rule(int bits) { g_dual_rule = bits; }
 
 /* Primal extension (NOT the reference's rule, off by default; eo_set_primal_rule(1)): steepest-edge
  * pricing.  Every nonbasic position carries gamma_j = 1 + |B^-1 a_j|^2; the entering candidates are the reference's
- * (primal…:253-270) but the key that goes through the reference's fold (:271-287) is r_j^2 / gamma_j instead of |r_j|.
+ * (primal…:253-270) but the key that goes through the reference's fold (:271-287) is |r_j| / sqrt(gamma_j) instead of |r_j|.
  * gamma is exact at a basis that is a signed permutation (every phase-1 start: 1 + |a_j|^2) and starts at 1 otherwise
  * (a reference-framework reset); after a pivot (entering position q, leaving row r, alpha_q = B^-1 a_q, rho = row r of
  * B^-1, v = B^-T alpha_q) it is updated exactly (Goldfarb & Reid): with abar_j = (rho . a_j) / alpha_q[r],
@@ -1184,7 +1184,9 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
             else if (!pos && Nb[j] == EO_NB_LOWER) key = -rj;
             else if (Nb[j] == EO_NB_FREE) key = fabs(rj);
             else continue;
-            if (gamma) key = (rj * rj) / gamma[j]; /* extension: steepest edge */
+            if (gamma) key = fabs(rj) / sqrt(gamma[j]); /* extension: steepest edge.  |r_j| / sqrt(gamma_j), not its square: the fold
+                                                           * compares keys to within EPS, and squares of small reduced costs
+                                                           * all fall below it long before the optimum */
             if (!have) {
                 have = 1;
                 r1 = key;
