@@ -66,6 +66,8 @@ def parse():
                     help="1/0: also run config 4 (m=2000 n=5000, dual simplex) on one GPU and report it as `config4` "
                          "(-1: yes when the headline is config 3 and N = 1)")
     ap.add_argument("--config4-steps", type=int, default=2000)
+    ap.add_argument("--full-solve", type=int, default=1,
+                    help="1/0: also solve config 3 to optimality with the steepest-edge extension (`config3_full_solve_steepest_edge`, ~4 s)")
     ap.add_argument("--config4-reference", type=int, default=1,
                     help="1/0: also time the dual loop on the reference's own DualPhase1 arrays of the config-3 LP "
                          "(`config4_reference_phase1`; ~15 s of setup)")
@@ -476,6 +478,33 @@ def main():
             del c4r, flat4, f
         except Exception as ex:  # the headline must not depend on it
             c4ref = {"error": str(ex)[:300]}
+    c3se = None
+    if is_c3 and world == 1 and args.full_solve:
+        # config 3 to OPTIMALITY through the user API with the opt-in steepest-edge extension (ellp_opts.flags = 4; not the
+        # reference's pricing rule — its Dantzig rule needs 655 k pivots / 25 s for the same solve, tests/test_gpu_fullsolve.py);
+        # objective against the committed independent optimum (tests/golden/synth_optimum_*.json, SciPy-HiGHS)
+        try:
+            from ellp_amd import Bound, ConstraintOp, PrimalSimplexSolver, Problem, synth
+            A, b, c = synth.dense_lp(args.seed, 2000, 5000)
+            p = Problem()
+            ids = [p.add_var(float(c[j]), Bound.Lower(0.0)) for j in range(5000)]
+            for i in range(2000):
+                p.add_constraint(list(zip(ids, A[i].tolist())), ConstraintOp.Lte, float(b[i]))
+            t0 = time.perf_counter()
+            res = PrimalSimplexSolver.new(None, flags=4).solve(p)
+            dts = time.perf_counter() - t0
+            fxp = os.path.join(ROOT, "tests", "golden", f"synth_optimum_{args.seed}_2000x5000.json")
+            ref = json.load(open(fxp))["objective"] if os.path.exists(fxp) else None
+            c3se = {"workload": "config 3's LP solved to optimality, PrimalSimplexSolver::new(None).solve with steepest-edge pricing "
+                                "(an opt-in extension; set-up included: standard form, rank check on the device, both phases)",
+                    "status": res.kind, "iterations_phase1_phase2": list(res.iters), "solve_s": round(dts, 3),
+                    "objective": res.solution.obj() if res.kind == "optimal" else None, "reference_objective_highs": ref,
+                    "reference_rule_for_comparison": "Dantzig: 654,976 iterations, 24.8 s (profiles/r03_steepest_edge_time.json)"}
+            if c3se["objective"] is not None and ref:
+                c3se["rel_diff"] = abs(c3se["objective"] - ref) / abs(ref)
+            del A, p
+        except Exception as ex:  # the headline must not depend on it
+            c3se = {"error": str(ex)[:300]}
     c2 = None
     if is_c3 and world == 1:
         # BASELINE.json's config 2: netlib AFIRO through the user API (parse_mps -> PrimalSimplexSolver::new(None).solve),
@@ -593,6 +622,8 @@ def main():
         out["config4"] = c4
     if c4ref is not None:
         out["config4_reference_phase1"] = c4ref
+    if c3se is not None:
+        out["config3_full_solve_steepest_edge"] = c3se
     if c5 is not None:
         out["config5"] = c5
     if cpu:

@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o pmc --output-format csv -- python3 "$ROOT/bench.py" --steps 400 --warmup 50 --profile-steps 0 --cpu-pivots 0 --config5 0 --config4 0 "$@" > "$OUT/${TAG}_pmc_$C.log" 2>&1
+  rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o pmc --output-format csv -- python3 "$ROOT/bench.py" --steps 400 --warmup 50 --profile-steps 0 --cpu-pivots 0 --config5 0 --config4 0 --full-solve 0 "$@" > "$OUT/${TAG}_pmc_$C.log" 2>&1
 done
 python3 "$ROOT/tools/pmc_traffic.py" "$TAG" /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$@" > "$OUT/${TAG}_pmc_traffic.json"
 head -c 1500 "$OUT/${TAG}_pmc_traffic.json"
