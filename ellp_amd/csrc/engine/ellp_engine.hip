@@ -3728,11 +3728,11 @@ void ellp_engine_destroy(ellp_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
 #ifdef ELLP_DBG_STAMPS
     if (e->h_st && hipMemcpy(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess) {
-        long long t0 = e->h_st->dbg[0][0][0];
+        long long t0 = e->h_st->dbg[0][0][0] ? e->h_st->dbg[0][0][0] : e->h_st->dbg[1][0][0];
         for (int k = 0; k < 3; ++k)
             for (int b = 0; b < 4; ++b) {
                 fprintf(stderr, "stamps kernel %d blocksel %d:", k, b);
-                for (int sl = 0; sl < 5; ++sl) fprintf(stderr, " %8.2f", (double)(e->h_st->dbg[k][b][sl] - t0) / 100.0);
+                for (int sl = 0; sl < 8; ++sl) fprintf(stderr, " %8.2f", e->h_st->dbg[k][b][sl] ? (double)(e->h_st->dbg[k][b][sl] - t0) / 100.0 : -1.0);
                 fprintf(stderr, "\n");
             }
     }
