@@ -14,11 +14,20 @@
 // thread per column, coalesced because M = A^T is walked through A's own column-major storage:
 // M[r, j] = A[j + r*m]) and from the element-wise passes.  Not bandwidth-optimal — it does not
 // need to be: 4 launches per elimination step (tools/qr_time.py for timings).
+//
+// That arrangement is kept as the EXACT mode (ELLP_QR_EXACT=1; the bitwise tests run it).  The default is the FAST mode:
+// the same algorithm step for step — nalgebra's pivot rule needs the fully updated trailing block before the next
+// reflector is known, so the steps cannot be blocked into GEMMs — with the one-accumulator-per-column chains given up:
+// norms and dot products are reduced in parallel (fixed, run-to-run reproducible orders), which leaves the three passes
+// over the trailing block per step (read for the dots, read + write for the update with the next pivot search fused in)
+// running at memory speed.  Results differ from the host loop in the last bits of |R_ii|; pivots differ only where two
+// entries of the trailing block tie to within that rounding (rank detection is pinned end to end only).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -250,6 +259,141 @@ __global__ __launch_bounds__(256) void k_qr_update(double *A, int64_t m, int64_t
         atomicMax(reinterpret_cast<unsigned long long *>(cand + j), (unsigned long long)__double_as_longlong(best));
 }
 
+// ---------------------------------------------------------------------------------------------- FAST mode kernels
+// cand[j] = max_r |M[r, j]| over all rows: (column tile, row chunk) blocks, atomicMax on the bit pattern (cand zeroed before)
+constexpr int FQ_UNROLL = 8;
+__global__ __launch_bounds__(256) void k_fq_scan(const double *__restrict__ A, int64_t m, int64_t nv, int64_t rows_per, double *cand) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = (r0 + rows_per < nv) ? r0 + rows_per : nv;
+    double best = 0.0;
+    for (int64_t r = r0; r < r1; r += FQ_UNROLL) {
+        double v[FQ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FQ_UNROLL; ++u) v[u] = A[j + ((r + u < r1) ? r + u : r1 - 1) * m];
+#pragma unroll
+        for (int u = 0; u < FQ_UNROLL; ++u) best = fmax(best, fabs(v[u]));
+    }
+    atomicMax(reinterpret_cast<unsigned long long *>(cand + j), (unsigned long long)__double_as_longlong(best));
+}
+
+__device__ __forceinline__ double block_sum_1024(double v, double *s_w) {  // fixed order: lanes by xor butterfly, then the 16 waves in turn
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if (lane == 0) s_w[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += s_w[w];
+    return t;
+}
+
+// the reflector of dense.h ColPivQR with parallel norms
+__global__ __launch_bounds__(1024) void k_fq_reflect(double *xbuf, int64_t len, int64_t i, QrState *st, double *rdiag) {
+    __shared__ double s_w[16];
+    __shared__ double s_sf;
+    __shared__ int s_skip;
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int64_t r = tid; r < len; r += 1024) {
+        const double v = xbuf[r];
+        acc += v * v;
+    }
+    const double sqn = block_sum_1024(acc, s_w);
+    if (tid == 0) {
+        const double norm = sqrt(sqn);
+        const double x0 = xbuf[0];
+        const double signed_norm = (x0 < 0.0) ? -norm : norm;
+        const double factor = (sqn + fabs(x0) * norm) * 2.0;
+        rdiag[i] = norm;
+        xbuf[0] = x0 + signed_norm;
+        s_skip = factor == 0.0 ? 1 : 0;
+        s_sf = sqrt(factor);
+        st->skip = s_skip;
+    }
+    __syncthreads();
+    if (s_skip) return;
+    const double sf = s_sf;
+    acc = 0.0;
+    for (int64_t r = tid; r < len; r += 1024) {
+        const double v = xbuf[r] / sf;
+        xbuf[r] = v;
+        acc += v * v;
+    }
+    const double n2 = sqrt(block_sum_1024(acc, s_w));
+    if (n2 != 0.0)
+        for (int64_t r = tid; r < len; r += 1024) xbuf[r] = xbuf[r] / n2;
+}
+
+// part[chunk][j] = sum over the chunk's rows of x[r] * M[i + r, j]: one thread per column (coalesced along j), FQ_UNROLL
+// rows in flight, the chunks summed in order by k_fq_f2
+__global__ __launch_bounds__(256) void k_fq_dot(const double *__restrict__ A, int64_t m, int64_t nv, int64_t i, const double *__restrict__ xbuf,
+                                                const QrState *st, int64_t rows_per, double *__restrict__ part) {
+    const int64_t j = i + 1 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (st->skip || j >= m) return;
+    const int64_t len = nv - i;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = (r0 + rows_per < len) ? r0 + rows_per : len;
+    const double *cj = A + j + i * m;
+    double dot = 0.0;
+    for (int64_t r = r0; r < r1; r += FQ_UNROLL) {
+        double v[FQ_UNROLL], x[FQ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FQ_UNROLL; ++u) {
+            const int64_t rr = (r + u < r1) ? r + u : r1 - 1;
+            v[u] = cj[rr * m];
+            x[u] = (r + u < r1) ? xbuf[rr] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < FQ_UNROLL; ++u) dot += x[u] * v[u];
+    }
+    part[(int64_t)blockIdx.y * m + j] = dot;
+}
+__global__ __launch_bounds__(256) void k_fq_f2(int64_t m, int64_t i, const QrState *st, int nchunk, const double *__restrict__ part, double *f2, double *cand) {
+    const int64_t j = i + 1 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    cand[j] = 0.0;
+    double dot = 0.0;
+    if (!st->skip)
+        for (int c = 0; c < nchunk; ++c) dot += part[(int64_t)c * m + j];
+    f2[j] = -2.0 * dot;
+}
+
+// the update of k_qr_update with FQ_UNROLL rows in flight per thread
+__global__ __launch_bounds__(256) void k_fq_update(double *__restrict__ A, int64_t m, int64_t nv, int64_t i, const double *__restrict__ xbuf,
+                                                   const QrState *st, const double *__restrict__ f2, double *cand) {
+    const int64_t j = i + 1 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int64_t len = nv - i;
+    const int64_t r0 = (int64_t)blockIdx.y * UPD_R;
+    const int64_t r1 = (r0 + UPD_R < len) ? r0 + UPD_R : len;
+    double *cj = A + j + i * m;
+    const bool skip = st->skip != 0;
+    const double f = f2[j];
+    double best = 0.0;
+    for (int64_t r = r0; r < r1; r += FQ_UNROLL) {
+        double v[FQ_UNROLL], x[FQ_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FQ_UNROLL; ++u) {
+            const int64_t rr = (r + u < r1) ? r + u : r1 - 1;
+            v[u] = cj[rr * m];
+            x[u] = xbuf[rr];
+        }
+#pragma unroll
+        for (int u = 0; u < FQ_UNROLL; ++u) {
+            if (r + u >= r1) continue;
+            double w = v[u];
+            if (!skip) {
+                w = f * x[u] + w;
+                cj[(r + u) * m] = w;
+            }
+            if (r + u > 0) best = fmax(best, fabs(w));
+        }
+    }
+    if (best > 0.0)
+        atomicMax(reinterpret_cast<unsigned long long *>(cand + j), (unsigned long long)__double_as_longlong(best));
+}
+
 void set_err(char *errbuf, size_t len, const char *msg, hipError_t e) {
     if (errbuf && len) snprintf(errbuf, len, "%s: %s", msg, hipGetErrorString(e));
 }
@@ -268,14 +412,17 @@ extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const doubl
         return ELLP_ERR_DEVICE;
     }
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return ELLP_ERR_DEVICE;
-    double *dA = nullptr, *xbuf = nullptr, *cand = nullptr, *rdiag = nullptr, *f2 = nullptr;
+    const char *exact_env = getenv("ELLP_QR_EXACT");
+    const bool exact = exact_env && exact_env[0] == '1';
+    constexpr int MAXCHUNK = 64;
+    double *dA = nullptr, *xbuf = nullptr, *cand = nullptr, *rdiag = nullptr, *f2 = nullptr, *part = nullptr;
     int64_t *piv = nullptr;
     QrState *st = nullptr;
     hipStream_t stream = nullptr;
     hipError_t rc = hipSuccess;
     auto cleanup = [&] {
         if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
-        (void)hipFree(dA); (void)hipFree(xbuf); (void)hipFree(cand); (void)hipFree(rdiag); (void)hipFree(f2); (void)hipFree(piv); (void)hipFree(st);
+        (void)hipFree(dA); (void)hipFree(xbuf); (void)hipFree(cand); (void)hipFree(rdiag); (void)hipFree(f2); (void)hipFree(part); (void)hipFree(piv); (void)hipFree(st);
     };
 #define QCHK(expr)                                      \
     do {                                                \
@@ -296,17 +443,44 @@ extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const doubl
     QCHK(hipMalloc(reinterpret_cast<void **>(&st), sizeof(QrState)));
     QCHK(hipMemcpyAsync(dA, A, sizeof(double) * (size_t)(m * nv), hipMemcpyHostToDevice, stream));
     QCHK(hipMemsetAsync(st, 0, sizeof(QrState), stream));
-    hipLaunchKernelGGL(k_qr_scan, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, dA, m, nv, (int64_t)0, cand);
+    if (exact) {
+        hipLaunchKernelGGL(k_qr_scan, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, dA, m, nv, (int64_t)0, cand);
+    } else {
+        QCHK(hipMalloc(reinterpret_cast<void **>(&part), sizeof(double) * (size_t)(m * MAXCHUNK)));
+        QCHK(hipMemsetAsync(cand, 0, sizeof(double) * (size_t)m, stream));
+        const int64_t tiles = (m + 255) / 256;
+        int64_t nch = 2048 / tiles;
+        nch = nch < 1 ? 1 : (nch > (nv + 63) / 64 ? (nv + 63) / 64 : nch);
+        const int64_t rows_per = (nv + nch - 1) / nch;
+        hipLaunchKernelGGL(k_fq_scan, dim3((unsigned)tiles, (unsigned)((nv + rows_per - 1) / rows_per)), dim3(256), 0, stream, dA, m, nv,
+                           rows_per, cand);
+    }
     for (int64_t i = 0; i < mn; ++i) {
         hipLaunchKernelGGL(k_qr_swap, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, dA, m, nv, i, cand, xbuf,
                            st, piv);
-        hipLaunchKernelGGL(k_qr_reflect, dim3(1), dim3(256), 0, stream, xbuf, nv - i, i, st, rdiag);
+        if (exact) hipLaunchKernelGGL(k_qr_reflect, dim3(1), dim3(256), 0, stream, xbuf, nv - i, i, st, rdiag);
+        else hipLaunchKernelGGL(k_fq_reflect, dim3(1), dim3(1024), 0, stream, xbuf, nv - i, i, st, rdiag);
         if (i + 1 < m) {
             const int64_t ncol = m - i - 1, len = nv - i;
-            hipLaunchKernelGGL(k_qr_dot, dim3((unsigned)((ncol + DOT_COLS - 1) / DOT_COLS)), dim3(64), 0, stream, dA, m, nv, i, xbuf, st,
-                               f2, cand);
-            hipLaunchKernelGGL(k_qr_update, dim3((unsigned)((ncol + 255) / 256), (unsigned)((len + UPD_R - 1) / UPD_R)),
-                               dim3(256), 0, stream, dA, m, nv, i, xbuf, st, f2, cand);
+            if (exact) {
+                hipLaunchKernelGGL(k_qr_dot, dim3((unsigned)((ncol + DOT_COLS - 1) / DOT_COLS)), dim3(64), 0, stream, dA, m, nv, i, xbuf, st,
+                                   f2, cand);
+                hipLaunchKernelGGL(k_qr_update, dim3((unsigned)((ncol + 255) / 256), (unsigned)((len + UPD_R - 1) / UPD_R)),
+                                   dim3(256), 0, stream, dA, m, nv, i, xbuf, st, f2, cand);
+            } else {
+                const int64_t tiles = (ncol + 255) / 256;
+                int64_t nch = 2048 / tiles;  // enough blocks to fill the device, at most MAXCHUNK partial sums per column
+                const int64_t maxch = (len + 63) / 64;
+                nch = nch > MAXCHUNK ? MAXCHUNK : nch;
+                nch = nch > maxch ? maxch : nch;
+                nch = nch < 1 ? 1 : nch;
+                const int64_t rows_per = (len + nch - 1) / nch;
+                const int64_t nchunk = (len + rows_per - 1) / rows_per;
+                hipLaunchKernelGGL(k_fq_dot, dim3((unsigned)tiles, (unsigned)nchunk), dim3(256), 0, stream, dA, m, nv, i, xbuf, st, rows_per, part);
+                hipLaunchKernelGGL(k_fq_f2, dim3((unsigned)tiles), dim3(256), 0, stream, m, i, st, (int)nchunk, part, f2, cand);
+                hipLaunchKernelGGL(k_fq_update, dim3((unsigned)tiles, (unsigned)((len + UPD_R - 1) / UPD_R)), dim3(256), 0, stream, dA, m, nv,
+                                   i, xbuf, st, f2, cand);
+            }
         }
     }
     QCHK(hipGetLastError());

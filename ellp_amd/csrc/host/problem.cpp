@@ -14,9 +14,10 @@ namespace {
 using dense::Index;
 
 // `A.transpose().col_piv_qr()` (standard_form.rs:142).  Large matrices go to the device
-// (ellp_hip_qr_transposed: the same arithmetic, bitwise — ~2 n m^2 flop are a minute of one host
-// core at m=2000, n=7000); small ones, and any matrix when no HIP device is present, use the host
-// loop.  ELLP_QR_DEVICE=1 / 0 forces the choice (tests).
+// (ellp_hip_qr_transposed: the same steps with the same pivot rule, sums reduced in parallel; bitwise the
+// host loop with ELLP_QR_EXACT=1 — ~2 n m^2 flop are a minute of one host core at m=2000, n=7000); small
+// ones, and any matrix when no HIP device is present, use the host loop.  ELLP_QR_DEVICE=1 / 0 forces
+// the choice (tests).
 dense::ColPivQR col_piv_qr_of_transpose(const dense::Matrix &A) {
     const char *force = std::getenv("ELLP_QR_DEVICE");
     const bool want_device = force ? force[0] == '1' : (A.rows * A.cols >= (Index)1 << 20);
