@@ -132,6 +132,7 @@ struct DevState {
     int32_t se_valid, se_neg;
     int64_t se_q;
     double se_arq, se_gq;
+    unsigned long long mbox_gen;  // mailbox transport (ellp_shard.inc): the last exchange that ran
 #ifdef ELLP_DBG_STAMPS
     long long dbg[3][4][8];  // [kernel][block selector][stamp] wall_clock64 (100 MHz) — dev builds only
 #endif
@@ -2810,7 +2811,6 @@ struct ellp_engine {
     double **d_peer_slots = nullptr;      // device arrays of the peers' mapped bases
     unsigned long long **d_peer_flags = nullptr;
     std::vector<void *> ipc_opened;
-    unsigned long long mgen = 0;
     uint64_t full_exchanges = 0, column_requests = 0;
     // small LPs (m <= 128): the reference's LU-per-iteration loop in one persistent workgroup (ellp_small.inc)
     bool small = false;      // run() uses k_small
@@ -3939,7 +3939,12 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         }
         e->ftran_lds = sizeof(double) * (size_t)e->nblocks + 16;
         e->refactor_period = e->opts.refactor_period > 0 ? e->opts.refactor_period : 0;
-        e->ill_tol = (m <= 512) ? 1e-3 : 0.0;
+        // reactive maintenance after a tiny pivot (|alpha_r| < ill_tol * max|alpha|): small LPs, and steepest edge at any
+        // size — its longer steps meet such pivots often enough that at config 5 a variable once left the basis 0.03
+        // off its bound between two looks of the drift monitor; costs the look-ahead of the run loop
+        const bool se_wanted = kind == ELLP_ENGINE_PRIMAL && (e->opts.flags & ELLP_FLAG_PRIMAL_STEEPEST_EDGE);
+        e->ill_tol = (m <= 512 || se_wanted) ? 1e-3 : 0.0;
+        if (const char *it = getenv("ELLP_ILL_TOL")) e->ill_tol = atof(it);  // diagnostics
         // drift monitor: only where refreshes are rare (period > 64), four checks per period; one GEMV
         // over A_B + a one-block fold, ~70 us at config 3 (0.7 % of the loop)
         {
@@ -4112,6 +4117,9 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         hipLaunchKernelGGL(k_resync_rhs, dim3((unsigned)((e->ld + 255) / 256)), dim3(256), 0, e->stream, ra);
         hipLaunchKernelGGL(k_phase1_art, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->tvec, e->A_B, e->x,
                            e->B_index, m, e->ld);
+        // the carried objective (and the trace) start from c . x WITH the artificials at |b~_i|, not from the host's value
+        hipLaunchKernelGGL(k_primal_obj, dim3(1), dim3(1024), 0, e->stream, e->c_B, e->c_N, e->x, e->B_index, e->N_index, e->m,
+                           e->nN, e->st);
     }
     // dual: initial dual feasibility assertion (dual…:139-151) — host side, data is in hand
     if (kind == ELLP_ENGINE_DUAL) {
@@ -5386,12 +5394,12 @@ ellp_status shard_exchange(ellp_engine *e, const double *src, double *dst, int64
         return ELLP_OPTIMAL;
     }
     if (e->transport == 2) {
-        e->mgen += 1;
-        MboxArgs a{e->d_peer_slots, e->d_peer_flags, src, dst, e->st, n, e->rank, e->world, e->mgen, 300000000LL /* 3 s */};
+        MboxArgs a{e->d_peer_slots, e->d_peer_flags, src, dst, e->st, n, e->rank, e->world, 300000000LL /* 3 s */};
         // the slot stride is slot_doubles, not n: both sides use slot_doubles
         a.n = n;
         hipLaunchKernelGGL(k_mbox_push, dim3((unsigned)e->world), dim3(256), 0, e->stream, a, e->slot_doubles);
         hipLaunchKernelGGL(k_mbox_wait, dim3((unsigned)e->world), dim3(256), 0, e->stream, a, e->slot_doubles);
+        hipLaunchKernelGGL(k_mbox_commit, dim3(1), dim3(1), 0, e->stream, e->st);
         return ELLP_OPTIMAL;
     }
     if (e->transport == 1 && e->comm && e->rccl) {

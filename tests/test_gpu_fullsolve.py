@@ -9,7 +9,9 @@ Tolerances (the stated f64 tolerances of this repository, README.md): objective 
 config 3 (2000 x 5000, primal): ~6.6e5 pivots, ~30 s of GPU — runs in the routine suite.
 config 5 (4000 x 40000, primal): 2.77e6 pivots, 12 minutes of GPU — marked slow: run it with ELLP_SLOW=1 (and let it print: a
 silent run of that length is taken for hung); the result of the run made for this repository (tools/seam_solve.py, the same
-solve with the hand-off on the device) is profiles/r03_full_solve_c5_dantzig.json: objective rel. 6e-15, max |dx| 1.7e-9."""
+solve with the hand-off on the device) is profiles/r03_full_solve_c5_dantzig.json: objective rel. 6e-15, max |dx| 1.7e-9.
+The same LP under the steepest-edge extension: 2.1e5 pivots, 81 s in the loops, objective rel. 1.7e-14, max |dx| 1.9e-9
+(profiles/r03_full_solve_c5_steepest_edge.json)."""
 import json
 import os
 import time
@@ -69,8 +71,10 @@ def test_c3_full_solve_matches_committed_optimum():
 
 
 @pytest.mark.slow
-def test_c5_full_solve_matches_committed_optimum():
-    """config 5 at the seam: phase 1 and phase 2 as two solve_with_initial calls on the arrays the reference's phases hand
+@pytest.mark.parametrize("flags", [0, 4], ids=["dantzig", "steepest-edge"])
+def test_c5_full_solve_matches_committed_optimum(flags):
+    """flags = 4: the steepest-edge extension (2.1e5 pivots, 90 s; profiles/r03_full_solve_c5_steepest_edge.json).
+    config 5 at the seam: phase 1 and phase 2 as two solve_with_initial calls on the arrays the reference's phases hand
     over (ellp_amd/synth.py builds them directly: 160 M coefficients through the Python Problem API would take longer than
     the solve), in slices so that progress is visible"""
     from ellp_amd import _engine as E
@@ -83,10 +87,10 @@ def test_c5_full_solve_matches_committed_optimum():
     f = flat
     for phase in (1, 2):
         fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"])
-        eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+        eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, flags=flags))
         st, loop_s = E.MAXITER, 0.0
         while st == E.MAXITER:
-            st, stats, msg = eng.run(100000)
+            st, stats, msg = eng.run(100000 if flags == 0 else 20000)
             loop_s += stats.t_loop_s
             print(f"phase {phase}: {int(stats.iters)} iterations, {loop_s:.1f} s, objective {stats.obj:.12g}", flush=True)
         eng.read_point()
@@ -99,13 +103,13 @@ def test_c5_full_solve_matches_committed_optimum():
             f = synth.primal_phase2_from(flat, fp.x, fp.B, fp.N, fp.Nb)
     obj = fp.obj()
     x = fp.x[:n]
-    rec = {"config": "c5", "seed": seed, "m": m, "n": n, "status": "optimal", "objective": obj, "fixture_objective": fx["objective"],
+    rec = {"config": "c5", "flags": flags, "seed": seed, "m": m, "n": n, "status": "optimal", "objective": obj, "fixture_objective": fx["objective"],
            "rel_diff_objective": abs(obj - fx["objective"]) / abs(fx["objective"]), "max_abs_diff_x": float(np.abs(x - x_ref).max()),
            "iterations_phase1_phase2": iters, "loop_s_phase1_phase2": [round(v, 2) for v in secs],
            "pivots_per_s_in_the_loops": round(sum(iters) / sum(secs), 1), "wall_s": round(time.perf_counter() - t0, 1)}
     out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "full_solve_c5.json"), "w") as fh:
+    with open(os.path.join(out, f"full_solve_c5_flags{flags}.json"), "w") as fh:
         json.dump(rec, fh)
     print(json.dumps(rec))
     assert abs(obj - fx["objective"]) <= 1e-9 * abs(fx["objective"]), rec
