@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
     long long bestpos = -1;
     int buf = 0;
     // unit columns (PriceArgs::vs_row): every wave fetches the flags of the block's columns itself (lane l: column j0 + l)
-    const bool use_vs = MODE == 0 && a.vs_row != nullptr;
+    const bool use_vs = a.vs_row != nullptr;  // primal: u[row]; dual: rho[row] — one product instead of a column of zeros
     int sgl = -1;
     double svl = 0.0;
     if (use_vs && j0 + lane < j1) {
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
     double best = (MODE == 0) ? -INFINITY : INFINITY;  // lanes 0 and 1 own the pair's two columns
     long long bestpos = -1;
     // unit columns (PriceArgs::vs_row): lane l holds the flag of column j0 + l
-    const bool use_vs = MODE == 0 && a.vs_row != nullptr;
+    const bool use_vs = a.vs_row != nullptr;  // primal: u[row]; dual: rho[row] — one product instead of a column of zeros
     int sgl = -1;
     double svl = 0.0;
     if (use_vs && j0 + lane < j1) {
@@ -3022,7 +3022,7 @@ void launch_price(ellp_engine *e) {
     a.block0 = e->rank * e->nbs;
     a.eps = e->eps;
     a.pp_on = e->pp_P > 1 ? 1 : 0;
-    a.vs_row = (MODE == 0 && !(e->opts.flags & ELLP_FLAG_DENSE_PRICING)) ? e->vs_row : nullptr;
+    a.vs_row = !(e->opts.flags & ELLP_FLAG_DENSE_PRICING) ? e->vs_row : nullptr;
     a.vs_val = a.vs_row ? e->vs_val : nullptr;
     if (MODE == 1 && e->dual_fold) {
         a.dp_seq = e->dual_seq;
@@ -4138,10 +4138,9 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     }
     e->dual_maxviol = (kind == ELLP_ENGINE_DUAL && (e->opts.flags & ELLP_FLAG_DUAL_MAX_VIOLATION)) ? 1 : 0;
     e->se = kind == ELLP_ENGINE_PRIMAL && (e->opts.flags & ELLP_FLAG_PRIMAL_STEEPEST_EDGE) && n_N > 0 && e->pp_P <= 1;
-    // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the primal
-    // pricing kernels consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
-    if (kind == ELLP_ENGINE_PRIMAL && n_N > 0 &&
-        (e->se || (!(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr))) {
+    // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the pricing
+    // kernels of both loops consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
+    if (n_N > 0 && (e->se || (!(e->opts.flags & ELLP_FLAG_DENSE_PRICING) && getenv("ELLP_NO_UNIT_COLUMNS") == nullptr))) {
         if (dmalloc(e, &e->vs_row, (size_t)n_c) == hipSuccess && dmalloc(e, &e->vs_val, (size_t)n_c) == hipSuccess &&
             dmalloc(e, &e->pos_hint, (size_t)n_N + 64) == hipSuccess) {
             ECHK(hipMemsetAsync(e->vs_row, 0xff, sizeof(int32_t) * (size_t)n_c, e->stream));
