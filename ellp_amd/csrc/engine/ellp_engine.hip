@@ -975,6 +975,8 @@ constexpr int FC_SLOTS = 16;
 // ratio argmin over the per-block minima (dual…:279, min_by keeps the FIRST minimum).
 // Epilogue MODE 0: the wave that produced d_i also evaluates the ratio lambda_i of basic row i
 // by bound kind (primal…:320-367) so that k_update2's fold only reads three flat arrays.
+#include "ellp_shard_select.inc"
+
 struct Ftran2Args {
     const double *W0, *W1, *A_N;
     Xchg xc;
@@ -990,6 +992,11 @@ struct Ftran2Args {
     double eps;
     const double *aq_cur;  // column-sharded engines: the entering position is st->sh_q (k_sh_select), its column is here
     int pp_on;             // partial pricing (DevState::pp_*)
+    // column-sharded engines, compact exchange: the selection runs HERE, in every block's prologue, on the gathered packs
+    // (null: k_sh_select has run); block 0 leaves the column in aq_out for k_update2 and commits the mailbox generation
+    const double *sel_packs;
+    double *aq_out;
+    int sel_world, mbox_commit;
 };
 
 // NT = double2 per lane that hold one row (ceil(ld/128)); NT == 0: rows are streamed instead
@@ -1037,8 +1044,25 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         k0 = a.kind[bi0];
         lbi0 = a.lb[bi0];
         ubi0 = a.ub[bi0];
-        if (tid == 0) s_q = st->sh_q;
-        lds_barrier();
+        if (a.sel_packs) {
+            if (wave == 0) {
+                const WaveSelect ws = shard_select_wave(a.sel_packs, a.sel_world, a.ld, a.eps, lane);
+                if (lane == 0) {
+                    s_q = ws.verdict ? -2 : ws.q;
+                    s_nh = ws.src_rank;
+                    s_band = ws.src_c;
+                }
+            }
+            lds_barrier();
+            if (blockIdx.x == 0 && tid == 0) {
+                if (a.mbox_commit) st->mbox_gen += 1;  // the packs have been consumed (also when they were not conclusive)
+                if (s_q == -2) st->status = ST_NEED_FULL;
+            }
+            if (s_q == -2) return;
+        } else {
+            if (tid == 0) s_q = st->sh_q;
+            lds_barrier();
+        }
     } else if (MODE == 0) {
         double *s_bk = reinterpret_cast<double *>(smem);
         double tmax = -INFINITY;
@@ -1258,7 +1282,10 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
     }
     const int at_lower = (MODE == 0) ? (a.Nb[q] == ELLP_NB_LOWER ? 1 : 0) : 0;
     const double sgn = at_lower ? -1.0 : 1.0;
-    const double2 *col = reinterpret_cast<const double2 *>((MODE == 0 && a.aq_cur) ? a.aq_cur : a.A_N + q * a.ld);
+    const double *sel_rec = (MODE == 0 && a.aq_cur && a.sel_packs)
+                                ? a.sel_packs + (int64_t)s_nh * pack_doubles(a.ld) + SH_HDR + (int64_t)s_band * (SH_REC + a.ld)
+                                : nullptr;  // the winner's record: key, N.index, position, r_q, then its column
+    const double2 *col = reinterpret_cast<const double2 *>(sel_rec ? sel_rec + SH_REC : ((MODE == 0 && a.aq_cur) ? a.aq_cur : a.A_N + q * a.ld));
     bool first = true;
     for (int64_t i = wave_global; i < a.m; i += nwaves, first = false) {
         const double2 *row = reinterpret_cast<const double2 *>(W + i * a.ld);
@@ -1328,6 +1355,10 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         }
     }
     STAMP(1, 3);
+    if (sel_rec && blockIdx.x == 0) {  // k_update2 and the drift monitor take the entering column from aq_cur
+        double2 *dst = reinterpret_cast<double2 *>(a.aq_out);
+        for (int64_t t = tid; t < half; t += 256) dst[t] = col[t];
+    }
     if (blockIdx.x == 0 && tid == 0) {  // commit the decision for k_update2
         ELLP_CHECK(st, q >= 0 && q < a.nN, 9101);
         ELLP_CHECK(st, MODE == 0 || (st->lr >= 0 && st->lr < a.m), 9102);
@@ -1337,7 +1368,7 @@ __global__ __launch_bounds__(256) void k_ftran2(Ftran2Args a) {
         if (MODE == 0) {
             const int64_t jq = a.N_index[q];
             st->s_jq = jq;
-            st->s_rq = a.aq_cur ? st->sh_rq : a.xc.r(q);
+            st->s_rq = sel_rec ? sel_rec[3] : (a.aq_cur ? st->sh_rq : a.xc.r(q));
             const int kk = a.kind[jq];  // primal…:305-311
             st->s_lambda0 = (kk == ELLP_BOUND_TWOSIDED) ? a.ub[jq] - a.lb[jq] : (kk == ELLP_BOUND_FIXED ? 0.0 : INFINITY);
         } else {
@@ -2800,6 +2831,8 @@ struct ellp_engine {
     int64_t own0 = 0, own1 = 0;          // nonbasic positions stored and priced here
     double *A_N_store = nullptr;          // the allocation behind the virtual base e->A_N
     double *packs = nullptr, *aq_cur = nullptr;  // gathered packs (world * pack_doubles), entering column
+    bool sel_in_ftran = false;  // this k_ftran2 launch runs the compact selection itself (launch_sharded_iteration)
+    bool sel_commit = false;    // ... and commits the mailbox generation of the exchange in front of it
     int64_t slot_doubles = 0;             // doubles per exchange slot = max(pack, full pricing segment)
     int transport = 0;                    // 0 none, 1 RCCL, 2 peer-to-peer mailbox, 3 host callback (tests, gloo)
     ellp_exchange_fn xfn = nullptr;
@@ -3070,6 +3103,12 @@ void launch_ftran2(ellp_engine *e) {
     a.d = e->d; a.lam = e->lam; a.bidx = e->bidx; a.dpos = e->dpos;
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.cpb = e->cpb; a.eps = e->eps;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr;
+    if (MODE == 0 && e->colshard && e->sel_in_ftran) {
+        a.sel_packs = e->packs; a.aq_out = e->aq_cur; a.sel_world = e->world; a.mbox_commit = e->sel_commit ? 1 : 0;
+    }
+    if (MODE == 0 && e->colshard && e->sel_in_ftran) {
+        a.sel_packs = e->packs; a.aq_out = e->aq_cur; a.sel_world = e->world; a.mbox_commit = e->sel_commit ? 1 : 0;
+    }
     a.pp_on = (MODE == 0 && e->pp_P > 1) ? 1 : 0;
     const dim3 g(e->ftran_blocks), b(256);
     const int64_t nt = ((e->ld >> 1) + 63) / 64;  // double2 per lane for one row
@@ -5386,7 +5425,7 @@ ellp_status ellp_engine_mailbox_connect(ellp_engine *e, const void *all_handles,
 
 namespace {
 // all-gather `n` doubles per rank: src = this rank's segment, dst = world * n doubles (dst + rank * n may be src)
-ellp_status shard_exchange(ellp_engine *e, const double *src, double *dst, int64_t n, char *errbuf, size_t errlen) {
+ellp_status shard_exchange(ellp_engine *e, const double *src, double *dst, int64_t n, char *errbuf, size_t errlen, bool commit = true) {
     if (e->world == 1) {
         if (dst + (int64_t)e->rank * n != src)
             HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, e->stream));
@@ -5398,7 +5437,7 @@ ellp_status shard_exchange(ellp_engine *e, const double *src, double *dst, int64
         a.n = n;
         hipLaunchKernelGGL(k_mbox_push, dim3((unsigned)e->world), dim3(256), 0, e->stream, a, e->slot_doubles);
         hipLaunchKernelGGL(k_mbox_wait, dim3((unsigned)e->world), dim3(256), 0, e->stream, a, e->slot_doubles);
-        hipLaunchKernelGGL(k_mbox_commit, dim3(1), dim3(1), 0, e->stream, e->st);
+        if (commit) hipLaunchKernelGGL(k_mbox_commit, dim3(1), dim3(1), 0, e->stream, e->st);
         return ELLP_OPTIMAL;
     }
     if (e->transport == 1 && e->comm && e->rccl) {
@@ -5427,7 +5466,7 @@ ellp_status shard_exchange(ellp_engine *e, const double *src, double *dst, int64
     return ELLP_ERR_ARG;
 }
 
-void launch_pack(ellp_engine *e, int forced) {
+PackArgs pack_args(ellp_engine *e, int forced) {
     PackArgs a{};
     a.A_N = e->A_N; a.xc = Xchg{e->X, e->seg, e->nbs, e->cpb}; a.N_index = e->N_index;
     a.pack = e->packs + (int64_t)e->rank * pack_doubles(e->ld);
@@ -5437,7 +5476,16 @@ void launch_pack(ellp_engine *e, int forced) {
     if (mine > e->nbs) mine = e->nbs;
     if (mine < 0) mine = 0;
     a.nblk = mine; a.cpb = e->cpb; a.forced = forced; a.eps = e->eps;
-    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, e->stream, a);
+    return a;
+}
+void launch_pack(ellp_engine *e, int forced) {
+    hipLaunchKernelGGL(k_pack, dim3(1), dim3(256), 0, e->stream, pack_args(e, forced));
+}
+// mailbox transport: pack, push and wait of an iteration's compact exchange in one launch (k_sh_xchg)
+void launch_xchg_fused(ellp_engine *e) {
+    const int64_t pd = pack_doubles(e->ld);
+    MboxArgs a{e->d_peer_slots, e->d_peer_flags, nullptr, e->packs, e->st, pd, e->rank, e->world, 300000000LL /* 3 s */};
+    hipLaunchKernelGGL(k_sh_xchg, dim3((unsigned)(2 * e->world)), dim3(256), 0, e->stream, pack_args(e, 0), a, e->slot_doubles);
 }
 void launch_select(ellp_engine *e, int mode) {
     SelectArgs a{};
@@ -5473,15 +5521,28 @@ ellp_status launch_sharded_iteration(ellp_engine *e, char *errbuf, size_t errlen
         Prof p(e, ELLP_K_PRICE);
         launch_price<0>(e);
     }
+    // Launches of a sharded iteration: pricing | exchange | FTRAN (the selection in its prologue) | update — four on the
+    // mailbox transport (k_sh_xchg packs, pushes and waits in one), five over RCCL (k_pack, then the all-gather).
+    // ELLP_SHARD_SPLIT=1: the seven-launch form of rounds 1-2 (k_pack, push, wait, commit, k_sh_select), for A/B and tests.
+    static const bool split = getenv("ELLP_SHARD_SPLIT") && getenv("ELLP_SHARD_SPLIT")[0] == '1';
     {
         Prof p(e, ELLP_K_SELECT);
-        launch_pack(e, 0);
         const int64_t pd = pack_doubles(e->ld);
-        const ellp_status s = shard_exchange(e, e->packs + (int64_t)e->rank * pd, e->packs, pd, errbuf, errlen);
-        if (s != ELLP_OPTIMAL) return s;
-        launch_select(e, 1);
+        if (!split && e->world > 1 && e->transport == 2 && 2 * e->world <= 64 && e->world * SH_KC <= 64) {
+            launch_xchg_fused(e);
+            e->sel_commit = true;
+        } else {
+            launch_pack(e, 0);
+            const ellp_status s = shard_exchange(e, e->packs + (int64_t)e->rank * pd, e->packs, pd, errbuf, errlen, split || e->world * SH_KC > 64);
+            if (s != ELLP_OPTIMAL) return s;
+            e->sel_commit = !(split || e->world * SH_KC > 64) && e->world > 1 && e->transport == 2;
+        }
+        if (split || e->world * SH_KC > 64) launch_select(e, 1);
+        else e->sel_in_ftran = true;
     }
     launch_sharded_tail(e);
+    e->sel_in_ftran = false;
+    e->sel_commit = false;
     return ELLP_OPTIMAL;
 }
 }  // namespace
