@@ -68,7 +68,7 @@ def _random_flat(seed, which):
                          v.y, v.d)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, which="default"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -93,6 +93,8 @@ def _worker(rank, world, port, q):
             cases.append((f"random-dual-{seed}", E.ENGINE_DUAL, lambda seed=seed: _random_flat(seed, "dual"), 150))
         if world > 2:  # four ranks on one GPU: the primal cases (the dual is not column-sharded), one random LP
             cases = [c for c in cases if c[1] == E.ENGINE_PRIMAL and c[0] not in ("random-primal-305", "random-primal-311")]
+        if which == "c5":  # BASELINE.json's config 5 (4000 x 40000), its first 400 pivots, column-sharded over the mailbox
+            cases = [("primal-c5", E.ENGINE_PRIMAL, lambda: _flat(20260305, 4000, 40000), 400)]
         for name, kind, make, cap in cases:
             opts = E.default_opts(max_iter=None, device=0, pipeline=1)  # the explicit-inverse engine on both sides
             ref_fp = make()
@@ -107,6 +109,8 @@ def _worker(rank, world, port, q):
                 # mapping of the other process's memory; here both processes sit on GPU 0)
                 variants += [("colshard-callback", dict(colshard=True, exchange="callback")),
                              ("colshard-mailbox", dict(colshard=True, exchange="mailbox"))]
+            if which == "c5":
+                variants = [("colshard-mailbox", dict(colshard=True, exchange="mailbox"))]
             for vname, kw in variants:
                 fp = make()
                 sh = ShardedEngine(kind, fp, opts, **kw)
@@ -168,6 +172,40 @@ def test_sharded_engine_takes_the_same_pivots(world):
     # the degenerate random LPs must have driven the loop through its fall-back (ties below the gap) too
     if world == 2:
         assert full > 0 and cols > 0, (full, cols)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_config5_first_400_pivots(world):
+    """config 5's LP (A_N = 1.4 GB, sharded in storage over the ranks — all on this one GPU), the first 400 pivots of phase 1:
+    every rank ends on the unsharded engine's basis and point"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "c5")) for r in range(world)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        results = collect_results(q, procs, world, 400)
+    except Exception:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert len(results) == world
+    for rank, out in results:
+        r = out["primal-c5/colshard-mailbox"]
+        assert r["same_status"] and r["iters"] == r["iters_ref"] == 400, (rank, r)
+        assert r["same_B"] and r["same_N"] and r["same_x"], (rank, r)
+        assert r["info"]["transport"] == "mailbox"
+        lo, hi = r["info"]["own"]
+        assert hi - lo <= (44000 + world - 1) // world + 64, (rank, r["info"])
 
 
 def test_stepped_api_world1_matches_run():
