@@ -3416,6 +3416,7 @@ void launch_price2(ellp_engine *e, int use_pend) {
     a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.m = e->m; a.rpb = e->upd2_rows; a.use_pend = use_pend; a.ill_tol = e->ill_tol;
+    a.aq_cur = e->colshard ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     int mine = e->nblocks - a.p.block0;
     if (mine > e->nbs) mine = e->nbs;
@@ -3453,6 +3454,12 @@ void launch_ftran_eta(ellp_engine *e) {
     a.binfo = e->binfo; a.dpos = e->dpos;
     a.A_B = e->A_B; a.c_B = e->c_B; a.aq_save = e->aq_save; a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN;
     a.nblocks = e->nblocks; a.cpb = e->cpb; a.rows_per_block = e->upd2_rows; a.eps = e->eps;
+    if (e->colshard) {
+        a.aq_cur = e->aq_cur; a.aq_out = e->aq_cur;
+        if (e->sel_in_ftran) {
+            a.sel_packs = e->packs; a.sel_world = e->world; a.mbox_commit = e->sel_commit ? 1 : 0;
+        }
+    }
     const dim3 g(e->upd2_blocks + 1), b(256);
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
     if (nr <= 1) hipLaunchKernelGGL((k_ftran_eta<1>), g, b, e->ftran_lds, e->stream, a);
@@ -5313,8 +5320,15 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
         set_err(errbuf, errlen, "the columns are already sharded");
         return ELLP_ERR_ARG;
     }
+    // the two-launch pipeline stays on for a column-sharded engine (ELLP_SHARD_LAGGED=0: the three-launch kernels of rounds 1-2)
+    const bool keep_lagged = e->lagged && !(getenv("ELLP_SHARD_LAGGED") && getenv("ELLP_SHARD_LAGGED")[0] == '0') &&
+                             !(getenv("ELLP_SHARD_SPLIT") && getenv("ELLP_SHARD_SPLIT")[0] == '1');
     const ellp_status s0 = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // rank, world, nbs, seg, X
     if (s0 != ELLP_OPTIMAL) return s0;
+    if (keep_lagged) {
+        e->lagged = true;
+        e->lag_open = false;
+    }
     HIPCHK(hipSetDevice(e->device));
     const int64_t ld = e->ld;
     int64_t a0 = (int64_t)rank * e->nbs * e->cpb, a1 = (int64_t)(rank + 1) * e->nbs * e->cpb;
@@ -5496,6 +5510,18 @@ void launch_select(ellp_engine *e, int mode) {
 }
 // the part of an iteration behind the selection: FTRAN with the given column, drift monitor, eta update
 void launch_sharded_tail(ellp_engine *e) {
+    if (e->lagged) {  // two-launch pipeline: F applies the eta update of the pivot k_price2 has booked and forms d; the iteration stays open
+        {
+            Prof p(e, ELLP_K_FTRAN);
+            launch_ftran_eta(e);
+        }
+        launch_drift_check(e);
+        e->lag_open = true;
+        e->since_btran += 1;
+        e->since_refactor += 1;
+        e->enqueued += 1;
+        return;
+    }
     {
         Prof p(e, ELLP_K_FTRAN);
         launch_ftran2<0>(e);
@@ -5519,7 +5545,8 @@ ellp_status launch_sharded_iteration(ellp_engine *e, char *errbuf, size_t errlen
     }
     {
         Prof p(e, ELLP_K_PRICE);
-        launch_price<0>(e);
+        if (e->lagged) launch_price2(e, e->lag_open ? 1 : 0);
+        else launch_price<0>(e);
     }
     // Launches of a sharded iteration: pricing | exchange | FTRAN (the selection in its prologue) | update — four on the
     // mailbox transport (k_sh_xchg packs, pushes and waits in one), five over RCCL (k_pack, then the all-gather).

@@ -95,8 +95,11 @@ def _worker(rank, world, port, q, which="default"):
             cases = [c for c in cases if c[1] == E.ENGINE_PRIMAL and c[0] not in ("random-primal-305", "random-primal-311")]
         if which == "c5":  # BASELINE.json's config 5 (4000 x 40000), its first 400 pivots, column-sharded over the mailbox
             cases = [("primal-c5", E.ENGINE_PRIMAL, lambda: _flat(20260305, 4000, 40000), 400)]
+        if which == "lagged":  # the two-launch pipeline on both sides (forced: most of these LPs are below its default size)
+            cases = [c for c in cases if c[1] == E.ENGINE_PRIMAL]
         for name, kind, make, cap in cases:
-            opts = E.default_opts(max_iter=None, device=0, pipeline=1)  # the explicit-inverse engine on both sides
+            # the explicit-inverse engine on both sides: its three-launch kernels, or (lagged, c5) the two-launch pipeline
+            opts = E.default_opts(max_iter=None, device=0, pipeline=2 if which in ("lagged", "c5") else 1)
             ref_fp = make()
             ref = E.Engine(kind, ref_fp, opts)
             st_ref, stats_ref, _ = ref.run(cap)
@@ -111,6 +114,8 @@ def _worker(rank, world, port, q, which="default"):
                              ("colshard-mailbox", dict(colshard=True, exchange="mailbox"))]
             if which == "c5":
                 variants = [("colshard-mailbox", dict(colshard=True, exchange="mailbox"))]
+            if which == "lagged":
+                variants = variants[1:]  # the replicated form runs the stepped API, which drives the three-launch kernels
             for vname, kw in variants:
                 fp = make()
                 sh = ShardedEngine(kind, fp, opts, **kw)
@@ -170,6 +175,51 @@ def test_sharded_engine_takes_the_same_pivots(world):
                 full += r["info"]["full_exchanges"]
                 cols += r["info"]["column_requests"]
     # the degenerate random LPs must have driven the loop through its fall-back (ties below the gap) too
+    if world == 2:
+        assert full > 0 and cols > 0, (full, cols)
+
+
+def _run_world(world, which, timeout=400):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, which)) for r in range(world)]
+    for p in procs:
+        p.daemon = True
+        p.start()
+    try:
+        results = collect_results(q, procs, world, timeout)
+    except Exception:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+        assert p.exitcode == 0
+    assert len(results) == world
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_engine_on_the_two_launch_pipeline(world):
+    """the column-sharded loop on the two-launch pipeline (pricing with the ratio fold | exchange | eta update + FTRAN with the
+    selection in its prologue) against the unsharded two-launch engine: same kernels, same arithmetic, so the same pivots —
+    including the tie-heavy LP, whose packs are not conclusive (full exchange, column on request: the FTRAN launch is
+    enqueued again behind them)"""
+    results = _run_world(world, "lagged")
+    full = cols = 0
+    for rank, out in results:
+        assert any(k.startswith("primal-ties/") for k in out) and any(k.startswith("primal-wave/") for k in out)
+        for name, r in out.items():
+            assert r["same_status"] and r["status"] == r["expect"], (rank, name, r)
+            assert r["iters"] == r["iters_ref"], (rank, name, r)
+            assert r["same_B"] and r["same_N"] and r["same_x"], (rank, name, r)
+            full += r["info"]["full_exchanges"]
+            cols += r["info"]["column_requests"]
     if world == 2:
         assert full > 0 and cols > 0, (full, cols)
 

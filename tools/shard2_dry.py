@@ -20,7 +20,7 @@ from ellp_amd.dist import ShardedEngine
 f = synth.primal_phase1_flat(20260301, m, n)
 def fp():
     return E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"])
-opts = E.default_opts(max_iter=None, device=0, pipeline=1)
+opts = E.default_opts(max_iter=None, device=0, pipeline=int(os.environ.get("SHARD_PIPELINE", "0")))  # 0: the engine's default (two launches from m = 384), 1: three
 p = fp()
 sh = ShardedEngine(E.ENGINE_PRIMAL, p, opts, colshard=True, exchange="mailbox")
 sh.run(100)
