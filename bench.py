@@ -260,11 +260,13 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
 
     def make_engine(profile, f=None):
         if world > 1:
-            # the column-sharded loop runs the three-launch kernels; say so explicitly, so that the single-GPU replay
-            # of the self-check below can be built with the same pipeline (the two-launch pipeline sums the FTRAN dot
-            # products in another order: a tie could fall the other way and read as a divergence)
+            # primal: the column-sharded loop runs the pipeline the engine was created with (two launches from m = 384:
+            # pricing | exchange | eta update + FTRAN) and the single-GPU replay of the self-check below is built with
+            # the same options, so both sides run the same kernels.  dual: the replicated stepped loop drives the
+            # three-launch kernels; say so explicitly for both sides (the two-launch form sums the FTRAN dot products
+            # in another order: a tie could fall the other way and read as a divergence)
             from ellp_amd.dist import ShardedEngine
-            return ShardedEngine(kind, f or fp, opts_for(profile, pipeline=0))
+            return ShardedEngine(kind, f or fp, opts_for(profile, pipeline=None if solver == "primal" else 0))
         return E.Engine(kind, f or fp, opts_for(profile))
 
     # ---- timed region: tableau resident, W warm-up steps, then exactly K steps
@@ -308,7 +310,7 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
         same_as_single = None
         if rank == 0:
             fp1 = make_fp()
-            ref = E.Engine(kind, fp1, opts_for(0, pipeline=0))  # three launches, like the sharded loop
+            ref = E.Engine(kind, fp1, opts_for(0, pipeline=None if solver == "primal" else 0))  # the sharded loop's kernels
             ref.run(total_after)
             ref.read_point()
             ref.close()
@@ -358,7 +360,7 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
     # what the engine really moves per pivot: one pass over A_N, and ONE pass over B^-1 that reads and rewrites it
     # (two-launch forms, m >= 384: the eta update is fused with FTRAN; BTRAN is an O(m) update of u) — three-launch
     # form: + 8 m ld for the separate FTRAN read
-    two_pass = m >= 384 and world == 1 and args.pipeline != 0
+    two_pass = m >= 384 and (world == 1 or not dual) and args.pipeline != 0
     out["engine_bytes_per_pivot"] = 8.0 * ld * nN + (16.0 if two_pass else 24.0) * m * ld
     # what the engine moves per iteration: BTRAN is O(m) incremental, and with the two-kernel pipeline
     # the eta update and the next FTRAN share one pass over B^-1
