@@ -3423,8 +3423,32 @@ void launch_price2(ellp_engine *e, int use_pend) {
     if (mine < 0) mine = 0;
     const dim3 g(mine + P2_BOOK), b(256);
     const size_t lds = e->price2_lds;
+    if (e->colshard) {  // the sharded instantiations (ellp_lagged.inc, SH)
+        if (e->price_wave) {
+            hipLaunchKernelGGL((k_price2_wave<true>), g, b, lds + sizeof(double) * (size_t)e->ld, e->stream, a);
+            return;
+        }
+        if (e->price_nt) {
+            switch (e->priceT) {
+            case 1: hipLaunchKernelGGL((k_price2<1, true, true>), g, b, lds, e->stream, a); break;
+            case 2: hipLaunchKernelGGL((k_price2<2, true, true>), g, b, lds, e->stream, a); break;
+            case 4: hipLaunchKernelGGL((k_price2<4, true, true>), g, b, lds, e->stream, a); break;
+            case 8: hipLaunchKernelGGL((k_price2<8, true, true>), g, b, lds, e->stream, a); break;
+            default: hipLaunchKernelGGL((k_price2<16, true, true>), g, b, lds, e->stream, a); break;
+            }
+        } else {
+            switch (e->priceT) {
+            case 1: hipLaunchKernelGGL((k_price2<1, false, true>), g, b, lds, e->stream, a); break;
+            case 2: hipLaunchKernelGGL((k_price2<2, false, true>), g, b, lds, e->stream, a); break;
+            case 4: hipLaunchKernelGGL((k_price2<4, false, true>), g, b, lds, e->stream, a); break;
+            case 8: hipLaunchKernelGGL((k_price2<8, false, true>), g, b, lds, e->stream, a); break;
+            default: hipLaunchKernelGGL((k_price2<16, false, true>), g, b, lds, e->stream, a); break;
+            }
+        }
+        return;
+    }
     if (e->price_wave) {
-        hipLaunchKernelGGL(k_price2_wave, g, b, lds + sizeof(double) * (size_t)e->ld, e->stream, a);
+        hipLaunchKernelGGL((k_price2_wave<false>), g, b, lds + sizeof(double) * (size_t)e->ld, e->stream, a);
         return;
     }
     if (e->price_nt) {
@@ -3462,6 +3486,14 @@ void launch_ftran_eta(ellp_engine *e) {
     }
     const dim3 g(e->upd2_blocks + 1), b(256);
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
+    if (e->colshard) {  // the sharded instantiations (selection in the prologue instead of the entering fold)
+        if (nr <= 1) hipLaunchKernelGGL((k_ftran_eta<1, true>), g, b, e->ftran_lds, e->stream, a);
+        else if (nr <= 2) hipLaunchKernelGGL((k_ftran_eta<2, true>), g, b, e->ftran_lds, e->stream, a);
+        else if (nr <= 4) hipLaunchKernelGGL((k_ftran_eta<4, true>), g, b, e->ftran_lds, e->stream, a);
+        else if (nr <= 8) hipLaunchKernelGGL((k_ftran_eta<8, true>), g, b, e->ftran_lds, e->stream, a);
+        else hipLaunchKernelGGL((k_ftran_eta<0, true>), g, b, e->ftran_lds, e->stream, a);
+        return;
+    }
     if (nr <= 1) hipLaunchKernelGGL((k_ftran_eta<1>), g, b, e->ftran_lds, e->stream, a);
     else if (nr <= 2) hipLaunchKernelGGL((k_ftran_eta<2>), g, b, e->ftran_lds, e->stream, a);
     else if (nr <= 4) hipLaunchKernelGGL((k_ftran_eta<4>), g, b, e->ftran_lds, e->stream, a);

@@ -22,4 +22,5 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:14]:
     print(f'{r["Name"][:60]:60s} calls {r["Calls"]:>7s}  avg {float(r["AverageNs"]) / 1000:8.2f} us  {r["Percentage"]:>6s} %')
 PY
+rm -rf "$OUT/prof"
 exit $rc
