@@ -5348,6 +5348,10 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
         set_err(errbuf, errlen, "partial pricing is implemented for one GPU");
         return ELLP_ERR_ARG;
     }
+    if (e->se) {
+        set_err(errbuf, errlen, "steepest-edge pricing is implemented for one GPU");
+        return ELLP_ERR_ARG;
+    }
     if (e->colshard) {
         set_err(errbuf, errlen, "the columns are already sharded");
         return ELLP_ERR_ARG;

@@ -315,3 +315,13 @@ def test_run_sharded_needs_a_communicator():
     with pytest.raises(E.EllpHipError):
         eng.run_sharded(10)
     eng.close()
+
+
+def test_steepest_edge_engines_are_not_sharded():
+    """the sharded loop prices with the reference's rule only: asking for both is an argument error, not a silent Dantzig run"""
+    from ellp_amd import _engine as E
+    eng = E.Engine(E.ENGINE_PRIMAL, _flat(3, 200, 500), E.default_opts(max_iter=None, device=0, flags=4))
+    with pytest.raises(E.EllpHipError) as ei:
+        eng.shard_columns(0, 1)
+    assert "steepest" in str(ei.value)
+    eng.close()
