@@ -14,7 +14,8 @@ def fp():
                          f["B"], f["N"], f["Nb"])
 for name, make in (("engine.run", lambda: E.Engine(E.ENGINE_PRIMAL, fp(), E.default_opts(max_iter=None))),
                    ("sharded, library loop + ncclAllGather", lambda: ShardedEngine(E.ENGINE_PRIMAL, fp(), E.default_opts(max_iter=None), exchange="rccl")),
-                   ("sharded, python loop (no collective at world 1)", lambda: ShardedEngine(E.ENGINE_PRIMAL, fp(), E.default_opts(max_iter=None), exchange="torch"))):
+                   ("sharded, python loop (no collective at world 1)", lambda: ShardedEngine(E.ENGINE_PRIMAL, fp(), E.default_opts(max_iter=None), exchange="torch")),
+                   ("column-sharded loop, two-launch kernels + ncclAllGather", lambda: ShardedEngine(E.ENGINE_PRIMAL, fp(), E.default_opts(max_iter=None), exchange="rccl", colshard=True))):
     eng = make()
     eng.run(300)
     torch.cuda.synchronize()
@@ -22,5 +23,5 @@ for name, make in (("engine.run", lambda: E.Engine(E.ENGINE_PRIMAL, fp(), E.defa
     st, stats, msg = eng.run(3000)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{name:50s} {3000 / dt:9.1f} pivots/s  {1e6 * dt / 3000:7.2f} us/iteration")
+    print(f"{name:58s} {3000 / dt:9.1f} pivots/s  {1e6 * dt / 3000:7.2f} us/iteration  (exchange: {getattr(eng, 'exchange_name', '-')})")
     eng.close()
