@@ -194,7 +194,9 @@ def pmc_traffic(m, n, solver, dual):
         mode = "1" if dual else "0"
         for kname, kv in pm["kernels"].items():
             hit = False
-            if kname == "k_price2_wave" or kname.startswith("k_price2<"):  # two-launch pipeline: primal only
+            if kname.startswith("k_price2_wave") or kname.startswith("k_price2<"):  # two-launch pipeline: primal only
+                if kname.rstrip(">").endswith("true") and kname.startswith("k_price2_wave"):
+                    continue  # the column-sharded instantiation
                 hit = not dual
             elif kname.startswith("k_price_wave<"):
                 hit = kname[len("k_price_wave<"):].rstrip(">").strip() == mode
