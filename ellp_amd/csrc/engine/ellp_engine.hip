@@ -2831,6 +2831,7 @@ struct ellp_engine {
     int64_t own0 = 0, own1 = 0;          // nonbasic positions stored and priced here
     double *A_N_store = nullptr;          // the allocation behind the virtual base e->A_N
     double *packs = nullptr, *aq_cur = nullptr;  // gathered packs (world * pack_doubles), entering column
+    int32_t *se_perm = nullptr;  // steepest edge: device flag "the starting basis is a signed permutation"
     bool sel_in_ftran = false;  // this k_ftran2 launch runs the compact selection itself (launch_sharded_iteration)
     bool sel_commit = false;    // ... and commits the mailbox generation of the exchange in front of it
     int64_t slot_doubles = 0;             // doubles per exchange slot = max(pack, full pricing segment)
@@ -4299,7 +4300,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
     }
-    // steepest-edge weights (ellp_se.inc): exact at a signed-permutation basis, 1 otherwise
+    // steepest-edge weights (ellp_se.inc): exact — at a signed-permutation basis from the columns alone, otherwise from B^-1 (below)
     if (e->se) {
         if (!e->vs_row) {
             set_err(errbuf, errlen, "no device memory for the steepest-edge tables");
@@ -4313,6 +4314,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         ECHK(dmalloc(e, &perm, 4));
         ECHK(hipMemsetAsync(e->se_rho, 0, sizeof(double) * (size_t)ld, e->stream));
         ECHK(hipMemsetAsync(e->se_v, 0, sizeof(double) * (size_t)ld, e->stream));
+        e->se_perm = perm;
         hipLaunchKernelGGL(k_se_perm, dim3(1), dim3(256), 0, e->stream, e->B_index, m, e->vs_row, e->vs_val, perm);
         hipLaunchKernelGGL(k_se_init, dim3((unsigned)((n_N + 3) / 4)), dim3(256), 0, e->stream, e->A_N, ld, m, n_N, perm, e->se_gamma);
         if (e->opts.flags & ELLP_FLAG_DENSE_PRICING) {  // the table was only needed for the permutation test
@@ -4322,6 +4324,20 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     // initial B^-1 (k_small keeps none: its LU is redone every iteration, with the reference's guard)
     if (e->small) e->w_valid = false;
     else launch_refactor(e);
+    if (e->se && e->se_perm) {  // steepest-edge weights at a basis that is not a signed permutation: exact, from the inverse just built
+        const int64_t rt = (m + 63) / 64;
+        double *part = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&part), sizeof(double) * (size_t)(rt * n_N)) == hipSuccess) {
+            hipLaunchKernelGGL(k_se_exact_part, dim3((unsigned)((n_N + 63) / 64), (unsigned)rt), dim3(256), 0, e->stream, e->W, e->W2, e->A_N,
+                               e->st, m, ld, n_N, e->se_perm, part);
+            hipLaunchKernelGGL(k_se_exact_reduce, dim3((unsigned)((n_N + 255) / 256)), dim3(256), 0, e->stream, e->st, n_N, (int)rt,
+                               e->se_perm, part, e->se_gamma);
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipFree(part);
+        } else {
+            (void)hipGetLastError();  // no scratch memory: the weights stay at 1 (a reference-framework start)
+        }
+    }
     ECHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
     ECHK(hipStreamSynchronize(e->stream));
     ECHK(hipGetLastError());

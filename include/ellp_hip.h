@@ -97,7 +97,10 @@ typedef struct ellp_opts {
                                 bit 2 (ELLP_FLAG_PRIMAL_STEEPEST_EDGE), an EXTENSION, primal engines: steepest-edge pricing
                                 (exact Goldfarb-Reid weights, ellp_se.inc) instead of the reference's Dantzig rule
                                 (primal_simplex_solver.rs:253-287); restated in the oracle (eo_set_primal_rule(1)); runs on the
-                                three-launch explicit-inverse engine at every size */
+                                three-launch explicit-inverse engine at every size, with the reactive tiny-pivot maintenance
+                                on.  Meant for RESIDENT solves (both phases on one engine, ellp_engine_rephase): a second
+                                engine created with this flag at phase 1's end basis broke down at config 5's size (4000 x
+                                40000) — the ratio test has no pivot-size safeguard, as the reference's has none */
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */

@@ -92,7 +92,7 @@ static int g_dual_rule = 0;
 void eo_set_dual_rule(int bits) { g_dual_rule = bits; }
 
 /* Primal extension (NOT the reference's rule, off by default; eo_set_primal_rule(1)): steepest-edge
- * pricing.  Every nonbasic position carries gamma_j = 1 + |B^-1 a_j|^2; the entering candidates are the reference's
+ * pricing.  Every nonbasic position carries gamma_j = 1 + |B^-1 a_j|^2 (exact at the start, whatever the basis); the entering candidates are the reference's
  * (primal…:253-270) but the key that goes through the reference's fold (:271-287) is |r_j| / sqrt(gamma_j) instead of |r_j|.
  * gamma is exact at a basis that is a signed permutation (every phase-1 start: 1 + |a_j|^2) and starts at 1 otherwise
  * (a reference-framework reset); after a pivot (entering position q, leaving row r, alpha_q = B^-1 a_q, rho = row r of
@@ -1114,14 +1114,26 @@ int eo_primal_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double
             }
             if (cnt != 1) perm = 0;
         }
+        int have_lu = 0;
+        if (!perm && g_primal_rule == 1) { /* a general starting basis: exact weights 1 + |B^-1 a_j|^2 from one factorisation */
+            memcpy(f.lu, A_B, sizeof(double) * (size_t)(m * m));
+            f.p.len = 0;
+            lu_factor_inplace(&f);
+            have_lu = 1;
+        }
         for (int64_t j = 0; j < nN; ++j) {
             double g = 1.0;
+            const double *cj = A_N + j * m;
             if (perm && g_primal_rule == 1) {
-                const double *cj = A_N + j * m;
                 for (int64_t i = 0; i < m; ++i) g += cj[i] * cj[i];
+            } else if (have_lu) {
+                memcpy(se_v, cj, sizeof(double) * (size_t)m);
+                if (lu_solve(&f, se_v))
+                    for (int64_t i = 0; i < m; ++i) g += se_v[i] * se_v[i];
             }
             gamma[j] = g;
         }
+        if (have_lu) memset(se_v, 0, sizeof(double) * (size_t)m);
     }
     int status = EO_ERR_PANIC;
     uint64_t iter = 1;

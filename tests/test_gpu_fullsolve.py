@@ -74,9 +74,9 @@ def test_c3_full_solve_matches_committed_optimum():
 @pytest.mark.parametrize("flags", [0, 4], ids=["dantzig", "steepest-edge"])
 def test_c5_full_solve_matches_committed_optimum(flags):
     """flags = 4: the steepest-edge extension (2.1e5 pivots, 90 s; profiles/r03_full_solve_c5_steepest_edge.json).
-    config 5 at the seam: phase 1 and phase 2 as two solve_with_initial calls on the arrays the reference's phases hand
-    over (ellp_amd/synth.py builds them directly: 160 M coefficients through the Python Problem API would take longer than
-    the solve), in slices so that progress is visible"""
+    config 5 on the arrays the reference's phases hand over at the seam (ellp_amd/synth.py builds them directly: 160 M
+    coefficients through the Python Problem API would take longer than the solve), both phases on one resident engine, in
+    slices so that progress is visible"""
     from ellp_amd import _engine as E
     from ellp_amd import synth
     seed, m, n = 20260305, 4000, 40000
@@ -84,25 +84,30 @@ def test_c5_full_solve_matches_committed_optimum(flags):
     flat = synth.primal_phase1_flat(seed, m, n)
     t0 = time.perf_counter()
     iters, secs = [], []
-    f = flat
+    # both phases on ONE resident engine, the hand-off on the device (ellp_engine_rephase) — what the host mirror's
+    # PrimalSimplexSolver does.  (A second engine created at phase 1's end basis also works under the reference's rule; under
+    # steepest edge that start met a run of tiny pivots it did not recover from after 3e4 iterations — DESIGN.md §5.)
+    fp = E.FlatProblem(flat["m"], flat["n"], flat["n_c"], flat["A"], flat["c"], flat["b"], flat["kind"], flat["lb"], flat["ub"],
+                       flat["x"], flat["B"], flat["N"], flat["Nb"])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, flags=flags))
     for phase in (1, 2):
-        fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"])
-        eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, flags=flags))
         st, loop_s = E.MAXITER, 0.0
         while st == E.MAXITER:
             st, stats, msg = eng.run(100000 if flags == 0 else 20000)
             loop_s += stats.t_loop_s
             print(f"phase {phase}: {int(stats.iters)} iterations, {loop_s:.1f} s, objective {stats.obj:.12g}", flush=True)
-        eng.read_point()
-        eng.close()
         assert st == E.OPTIMAL, msg
         iters.append(int(stats.iters))
         secs.append(loop_s)
+        eng.read_point()
         if phase == 1:
             assert abs(fp.obj()) < 1e-7
-            f = synth.primal_phase2_from(flat, fp.x, fp.B, fp.N, fp.Nb)
-    obj = fp.obj()
+            f2 = synth.primal_phase2_from(flat, fp.x, fp.B, fp.N, fp.Nb)
+            eng.rephase(f2["c"], f2["kind"], f2["lb"], f2["ub"])
+    eng.close()
+    c_full = np.zeros(len(fp.x)); c_full[:n] = synth.dense_lp(seed, m, n)[2]
     x = fp.x[:n]
+    obj = float(c_full[:n] @ x)
     rec = {"config": "c5", "flags": flags, "seed": seed, "m": m, "n": n, "status": "optimal", "objective": obj, "fixture_objective": fx["objective"],
            "rel_diff_objective": abs(obj - fx["objective"]) / abs(fx["objective"]), "max_abs_diff_x": float(np.abs(x - x_ref).max()),
            "iterations_phase1_phase2": iters, "loop_s_phase1_phase2": [round(v, 2) for v in secs],

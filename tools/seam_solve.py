@@ -32,7 +32,12 @@ for phase in (1, 2):
         eng.read_point()
         assert abs(fp.obj()) < 1e-7, fp.obj()
         f2 = synth.primal_phase2_from(flat, fp.x, fp.B, fp.N, fp.Nb)
-        eng.rephase(f2["c"], f2["kind"], f2["lb"], f2["ub"])
+        if os.environ.get("SEAM_FRESH"):  # phase 2 on a NEW engine from the hand-over arrays (B^-1 rebuilt, steepest-edge weights initialised there)
+            eng.close()
+            fp = E.FlatProblem(f2["m"], f2["n"], f2["n_c"], f2["A"], f2["c"], f2["b"], f2["kind"], f2["lb"], f2["ub"], f2["x"], f2["B"], f2["N"], f2["Nb"])
+            eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, flags=flags))
+        else:
+            eng.rephase(f2["c"], f2["kind"], f2["lb"], f2["ub"])
 eng.read_point()
 res = eng.inverse_residual()
 eng.close()
