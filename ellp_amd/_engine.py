@@ -345,10 +345,12 @@ class Engine:
         err = C.create_string_buffer(512)
         s = lib().ellp_engine_read_point(self._h, _p(fp.x), _p(fp.B), _p(fp.N), _p(fp.Nb), _p(fp.y),
                                          _p(fp.d), err, 512)
-        # OPTIMAL: delivered; UNBOUNDED / ERR_PANIC / ERR_NAN: delivered, and completing the iteration the two-launch
-        # pipeline had left open ended the solve that way (include/ellp_hip.h)
+        # OPTIMAL: delivered.  UNBOUNDED / MAXITER: delivered, and completing the iteration the two-launch pipeline had left
+        # open ended the solve that way (include/ellp_hip.h) — kept in closing_status.  Every error code raises (the arrays
+        # are filled all the same: the caller may look at fp after catching): a point that came with ERR_NAN / ERR_PANIC /
+        # ERR_SINGULAR or any code this binding does not know is never returned as a success.
         self.closing_status = s
-        if s in (ERR_DEVICE, ERR_ARG, ERR_BAD_DIMS):
+        if s not in (OPTIMAL, UNBOUNDED, MAXITER):
             raise EllpHipError(s, err.value.decode())
         return fp
 
@@ -395,10 +397,14 @@ class Engine:
 
     def counters(self):
         """host-side maintenance counters (TAP_STATE tail)"""
-        v = self.tap(TAP_STATE, 22)
+        v = self.tap(TAP_STATE, 28)
         return dict(drift=v[12], drift_checks=int(v[13]), maint_requests=int(v[14]), refreshes=int(v[15]),
                     rebuilds=int(v[16]), resyncs=int(v[17]), last_refresh_residual=v[18], launches_per_iteration=int(v[19]),
-                    rebuild_shortcuts=int(v[20]), t_setup_s=float(v[21]))
+                    rebuild_shortcuts=int(v[20]), t_setup_s=float(v[21]),
+                    # certified hybrid (DESIGN.md §3.1c): is it on, guarded pivots handed to the exact kernel, terminal statuses
+                    # examined, of those not confirmed, loop bodies run by the exact kernel, rebuilds after a hand-over
+                    hybrid=bool(v[22]), hybrid_guards=int(v[23]), hybrid_certs=int(v[24]), hybrid_disagreed=int(v[25]),
+                    hybrid_exact_iters=int(v[26]), hybrid_rebuilds=int(v[27]))
 
     # ---- sharded / stepped driving (see ellp_amd/dist.py)
     def segment_doubles(self, world):

@@ -66,6 +66,13 @@ constexpr int ST_RUNNING = 100;
 // update.  The leader of the next pricing launch turns the flag into this status, so every later
 // kernel of the batch sees it from its first instruction and the rest of the batch is void.
 constexpr int ST_NEED_MAINT = 101;
+// internal, certified-hybrid engines (ellp_engine::hybrid): the pivot the ratio test chose is below the
+// guard (an explicit inverse is good to cond * 2^-53: a structural zero of B^-1 a_q comes out as ~1e-9 on ill-conditioned
+// bases, passes the reference's EPS tests, wins a degenerate ratio test and makes the basis singular).  NOTHING of the
+// iteration has been committed: every block of k_update2 takes the same decision from the same inputs and returns
+// before its first store, so — unlike ST_NEED_MAINT — the leader may write the status itself.  The host hands the
+// iteration to the LU-per-iteration kernel (exact_takeover).
+constexpr int ST_NEED_EXACT = 102;
 constexpr int WAVE = 64;
 
 struct DevState {
@@ -1610,6 +1617,7 @@ struct Update2Args {
     int update_u;
     int stage_lds;
     double ill_tol;   // > 0: after a pivot with |alpha_r| < ill_tol * max|alpha| stop for maintenance
+    double guard_abs; // > 0 (certified hybrid): a pivot with |alpha_r| < guard_abs is NOT taken, the loop stops with ST_NEED_EXACT
     double eps;
     const double *aq_cur;   // column-sharded engines: the entering column (A_N holds only positions [own0, own1))
     int64_t own0, own1;
@@ -1790,6 +1798,10 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
     if (r >= 0) {
         d_r = a.d[r];
         alpha_r = (MODE == 0 && at_lower) ? -d_r : d_r;
+        if (a.guard_abs > 0.0 && fabs(d_r) < a.guard_abs) {  // see ST_NEED_EXACT: every block returns, nothing is stored
+            if (blockIdx.x == 0 && tid == 0) st->status = ST_NEED_EXACT;
+            return;
+        }
         if (row_block) {
             if (NR > 0) {
                 const double2 *rho2 = reinterpret_cast<const double2 *>(src + r * a.ld);
@@ -2871,6 +2883,12 @@ struct ellp_engine {
     int mid_nt = 0;
     int64_t ldn = 0;
     double *LUa = nullptr, *Ut = nullptr, *A_Nt = nullptr;
+    // certified hybrid: the explicit-inverse loop with a pivot guard; every terminal status and every
+    // guarded iteration is handed to the LU-per-iteration kernel (k_mid) for up to exact_K iterations (exact_takeover)
+    bool hybrid = false;
+    double guard_abs = 0.0;
+    int exact_K = 8;
+    uint64_t hy_guards = 0, hy_certs = 0, hy_disagree = 0, hy_exact_iters = 0, hy_rebuilds = 0;
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
     int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
@@ -3107,9 +3125,6 @@ void launch_ftran2(ellp_engine *e) {
     if (MODE == 0 && e->colshard && e->sel_in_ftran) {
         a.sel_packs = e->packs; a.aq_out = e->aq_cur; a.sel_world = e->world; a.mbox_commit = e->sel_commit ? 1 : 0;
     }
-    if (MODE == 0 && e->colshard && e->sel_in_ftran) {
-        a.sel_packs = e->packs; a.aq_out = e->aq_cur; a.sel_world = e->world; a.mbox_commit = e->sel_commit ? 1 : 0;
-    }
     a.pp_on = (MODE == 0 && e->pp_P > 1) ? 1 : 0;
     const dim3 g(e->ftran_blocks), b(256);
     const int64_t nt = ((e->ld >> 1) + 63) / 64;  // double2 per lane for one row
@@ -3128,6 +3143,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd2_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
+    a.guard_abs = e->hybrid ? e->guard_abs : 0.0;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.count_iter = (MODE == 0 && e->lagged) ? 0 : 1;
     a.maxviol = e->dual_maxviol;
@@ -4240,18 +4256,14 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         const int pl = e->opts.pipeline;
         e->small_lds = small_lds_bytes(m, n_N);
         e->mid_lds = mid_lds_bytes(m, n_N);
-        // up to which size the exact loop is the DEFAULT (it is 20-80 x slower per iteration than the explicit-inverse
-        // engine at these sizes, and the only one that ends as the reference does on ill-conditioned LPs)
-        int64_t mid_auto = 512;
+        // up to which size the exact loop ALONE is the default: m <= 128 (k_small, factors in LDS, 1-5 x slower per iteration
+        // than the explicit-inverse engine).  Above that the default is the certified hybrid (below); pipeline = 3 or
+        // ELLP_MID_AUTO_MAX still select the LU-per-iteration kernel k_mid for whole solves up to 1024 rows (15-40 x slower).
+        int64_t mid_auto = SMALL_MAX_M;
         if (const char *ev = getenv("ELLP_MID_AUTO_MAX")) mid_auto = atoll(ev);
         const bool fits = e->small_lds > 0 || e->mid_lds > 0;
         const bool wanted = e->pp_P <= 1 && !e->se && (pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
                                                          e->opts.profile == 0 && (m <= SMALL_MAX_M || m <= mid_auto)));
-        if (pl == 3 && !fits) {
-            set_err(errbuf, errlen, "pipeline 3 (one persistent workgroup, LU every iteration) needs m <= %d", MID_MAX_M);
-            ellp_engine_destroy(e);
-            return ELLP_ERR_ARG;
-        }
         e->small = wanted && fits;
         e->mid = e->small && e->small_lds == 0;
         if (e->small && getenv("ELLP_SMALL_STAMPS") && !e->small_stamps) {
@@ -4290,12 +4302,35 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
             }
         }
     }
+    // Certified hybrid (restated in oracle/ellp_oracle.c: hybrid_run), the default for 128 < m <= 1024: the
+    // explicit-inverse loop on the three-launch pipeline (its ratio-test fold sits in front of every store of the iteration,
+    // so a guarded pivot can be refused by all blocks alike) with the pivot guard on; every terminal status and every
+    // guarded iteration is re-examined by the LU-per-iteration kernel k_mid from the same arrays (exact_takeover).  Off with
+    // an explicit pipeline, ELLP_FLAG_NO_CERTIFY, partial pricing, steepest edge, btran_mode 1 and on sharded engines.
+    if (!e->small && e->opts.pipeline == 0 && !(e->opts.flags & ELLP_FLAG_NO_CERTIFY) && e->mid_lds > 0 && n_N > 0 && e->pp_P <= 1 &&
+        !e->se && e->opts.btran_mode == 0 && getenv("ELLP_NO_HYBRID") == nullptr) {
+        e->mid_nt = mid_threads(m);
+        e->ldn = (n_N + 15) / 16 * 16;
+        const void *fn = mid_kernel(e->kind, e->mid_nt);
+        hipError_t ra = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->mid_lds);
+        if (ra == hipSuccess) ra = dmalloc(e, &e->LUa, (size_t)(ld * ld));
+        if (ra == hipSuccess) ra = dmalloc(e, &e->Ut, (size_t)(ld * ld));
+        if (ra == hipSuccess) ra = dmalloc(e, &e->A_Nt, (size_t)(ld * e->ldn));
+        if (ra == hipSuccess) {
+            e->hybrid = true;
+            e->guard_abs = 1e-7;
+            if (const char *v = getenv("ELLP_GUARD_ABS"); v && v[0]) e->guard_abs = atof(v);  // diagnostics
+            if (const char *v = getenv("ELLP_EXACT_K"); v && v[0] && atoi(v) > 0) e->exact_K = atoi(v);  // diagnostics
+        } else {
+            (void)hipGetLastError();  // no memory for the factors: the plain explicit-inverse engine
+        }
+    }
     // two launches per primal iteration from m = 1024 (ellp_lagged.inc), or on request
     {
         const int pl = e->opts.pipeline;
-        e->lagged = !e->small && !e->se && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
+        e->lagged = !e->small && !e->hybrid && !e->se && kind == ELLP_ENGINE_PRIMAL && e->opts.btran_mode == 0 && n_N > 0 && e->pp_P <= 1 &&
                     (pl == 2 || (pl == 0 && m >= 384));  // partial pricing runs on the three-launch pipeline; tools/pipeline_threshold.py for the size
-        e->dual_fused = !e->small && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 384));
+        e->dual_fused = !e->small && !e->hybrid && kind == ELLP_ENGINE_DUAL && n_N > 0 && ld <= 4096 && (pl == 2 || (pl == 0 && m >= 384));
         e->dual_fold = e->dual_fused && e->ill_tol <= 0.0 && getenv("ELLP_DUAL_FOLD_OFF") == nullptr;
         if (e->lagged && e->price_wave && ld > 4096) e->price_wave = false;  // k_price2_wave keeps u in 8 double2 per thread
         e->price2_lds = sizeof(double) * (size_t)((m + 63) / 64) + 16;
@@ -4419,6 +4454,32 @@ static ellp_status ensure_inverse(ellp_engine *e, char *errbuf, size_t errlen) {
     return ELLP_OPTIMAL;
 }
 
+// one launch of the LU-per-iteration kernel of ellp_mid.inc for up to `iters` loop bodies (run_small; exact_takeover)
+static hipError_t launch_mid(ellp_engine *e, uint64_t iters, int resync) {
+    const int64_t per = (int64_t)e->nbs * e->cpb;  // layout of the pricing buffer (Xchg, one segment)
+    MidArgs a{};
+    a.A_B = e->A_B; a.A_N = e->A_N; a.A_Nt = e->A_Nt; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
+    a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
+    a.kbuf = e->X + 2 * e->nbs;
+    a.rbuf = e->X + 2 * e->nbs + per;
+    a.LUa = e->LUa; a.Ut = e->Ut;
+    a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.ldn = e->ldn;
+    a.max_iters = iters;
+    a.nch = (int)((e->nN + 63) / 64);
+    a.eps = e->eps;
+    a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
+    a.stamps = e->small_stamps;
+    a.maxviol = e->dual_maxviol;
+    a.resync = resync;
+    a.b = e->b_dev;
+    // the row-major copy of A_N the pricing pass reads: made afresh at every launch (anything may have
+    // touched A_N in between: a hand-off, a sharding call, the other engine)
+    hipLaunchKernelGGL(k_mid_transpose, dim3((unsigned)((e->m + 31) / 32), (unsigned)((e->nN + 31) / 32)), dim3(256), 0,
+                       e->stream, e->A_N, e->A_Nt, e->m, e->ld, e->nN, e->ldn);
+    void *kargs[] = {&a};
+    return hipLaunchKernel(mid_kernel(e->kind, e->mid_nt), dim3(1), dim3((unsigned)e->mid_nt), kargs, e->mid_lds, e->stream);
+}
+
 // ellp_engine_run for the small path: launches of k_small, each good for up to 16384 iterations
 static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, size_t errlen) {
     HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
@@ -4429,25 +4490,7 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
     const int64_t per = (int64_t)e->nbs * e->cpb;  // layout of the pricing buffer (Xchg, one segment)
     while (remaining > 0) {
         if (e->mid) {
-            MidArgs a{};
-            a.A_B = e->A_B; a.A_N = e->A_N; a.A_Nt = e->A_Nt; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
-            a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
-            a.kbuf = e->X + 2 * e->nbs;
-            a.rbuf = e->X + 2 * e->nbs + per;
-            a.LUa = e->LUa; a.Ut = e->Ut;
-            a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.ldn = e->ldn;
-            a.max_iters = remaining < 4096 ? remaining : 4096;
-            a.nch = (int)((e->nN + 63) / 64);
-            a.eps = e->eps;
-            a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
-            a.stamps = e->small_stamps;
-            a.maxviol = e->dual_maxviol;
-            // the row-major copy of A_N the pricing pass reads: made afresh at every launch (anything may have
-            // touched A_N in between: a hand-off, a sharding call, the other engine)
-            hipLaunchKernelGGL(k_mid_transpose, dim3((unsigned)((e->m + 31) / 32), (unsigned)((e->nN + 31) / 32)), dim3(256), 0,
-                               e->stream, e->A_N, e->A_Nt, e->m, e->ld, e->nN, e->ldn);
-            void *kargs[] = {&a};
-            HIPCHK(hipLaunchKernel(mid_kernel(e->kind, e->mid_nt), dim3(1), dim3((unsigned)e->mid_nt), kargs, e->mid_lds, e->stream));
+            HIPCHK(launch_mid(e, remaining < 4096 ? remaining : 4096, 0));
         } else {
             SmallArgs a{};
             a.A_B = e->A_B; a.A_N = e->A_N; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x; a.y = e->y; a.dd = e->dd;
@@ -4516,6 +4559,98 @@ ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
 
 static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen);
 
+// Certified hybrid (restated in oracle/ellp_oracle.c, hybrid_run): the explicit-inverse loop has stopped — on a guarded
+// pivot (ST_NEED_EXACT: nothing of that iteration is committed), on a terminal status, or on an error of its own arithmetic
+// (singular rebuild, NaN, an assertion of the reference).  h_st is the drained device state.  The LU-per-iteration kernel
+// (k_mid: the reference's arithmetic on a fresh factorisation, primal…:173-189,289-292,404-406; dual…:241-246,281-284)
+// runs up to exact_K loop bodies from the same arrays; dual engines recompute x_B = A_B^-1 (b - A_N x_N) from that LU
+// first.  The loop body in which a terminal status was found is examined again, not counted twice.
+// Returns 0: nothing to do; 1: the loop goes on (status RUNNING, B^-1 rebuilt from the basis k_mid left);
+// 2: the solve has ended, *result holds the status k_mid found (certified, or corrected).
+static int exact_takeover(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
+    if (!e->hybrid || e->world != 1 || e->colshard) return 0;
+    const int s = e->h_st->status;
+    const bool guard = s == ST_NEED_EXACT;
+    const bool terminal = s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED;
+    const bool failed = s == ELLP_ERR_SINGULAR || s == ELLP_ERR_NAN || s == ELLP_ERR_PANIC;
+    if (!guard && !terminal && !failed) return 0;
+    DevState ns = *e->h_st;
+    uint64_t budget = remaining;
+    if (terminal && ns.iters > 0) {
+        ns.iters -= 1;
+        budget += 1;
+    }
+    if (budget == 0) return 0;  // a guarded pivot at the very end of the caller's slice: the next slice starts here
+    ns.status = ST_RUNNING;
+    ns.nan_flag = 0;
+    ns.tiny = 0;
+    ns.tiny_p = 0;
+    ns.fin = 0;
+    ns.need_rebuild = 0;
+    ns.panic_code = 0;
+    auto fail = [&](hipError_t rc) {
+        set_err(errbuf, errlen, "HIP error %s in the hand-over to the exact kernel", hipGetErrorString(rc));
+        *result = ELLP_ERR_DEVICE;
+        return 2;
+    };
+    hipError_t rc;
+    *e->h_st = ns;
+    if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return fail(rc);
+    const uint64_t K = budget < (uint64_t)e->exact_K ? budget : (uint64_t)e->exact_K;
+    if ((rc = launch_mid(e, K, e->kind == ELLP_ENGINE_DUAL ? 1 : 0)) != hipSuccess) return fail(rc);
+    if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
+    if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
+    const uint64_t did = e->h_st->iters - ns.iters;
+    const int s2 = e->h_st->status;
+    e->hy_exact_iters += did;
+    if (guard) e->hy_guards += 1;
+    else {
+        e->hy_certs += 1;
+        if (!(s2 == s && did <= 1)) e->hy_disagree += 1;
+    }
+    if (getenv("ELLP_HYBRID_DEBUG"))
+        fprintf(stderr, "ellp hybrid: fast status %d at iteration %llu -> exact kernel, %llu iterations, status %d\n", s,
+                (unsigned long long)ns.iters, (unsigned long long)did, s2);
+    e->u_valid = false;
+    e->since_btran = 0;
+    e->maint_chain = 0;
+    e->enqueued = 0;
+    e->iters_seen = e->h_st->iters;
+    if (e->h_st->pivots != ns.pivots || failed) {
+        // the explicit inverse follows the basis (also when the solve has ended: a phase hand-off reads it)
+        static const int32_t running = ST_RUNNING;
+        if (s2 != ST_RUNNING) (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        launch_refactor(e);
+        e->hy_rebuilds += 1;
+        DevState after;
+        if ((rc = hipMemcpyAsync(&after, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
+        if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
+        prof_collect(e);
+        if (after.status != ST_RUNNING) {
+            if (s2 == ST_RUNNING) {  // the basis the exact kernel left fails the rebuild's guard: that is the loop's next LU
+                *e->h_st = after;
+                *result = status_message(after, errbuf, errlen);
+                return 2;
+            }
+            e->w_valid = false;
+        }
+        e->h_st->cur = after.cur;
+        if (s2 != ST_RUNNING) {
+            static int32_t keep;
+            keep = s2;
+            (void)hipMemcpyAsync(&e->st->status, &keep, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+            (void)hipMemcpyAsync(&e->st->panic_code, &e->h_st->panic_code, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+            (void)hipStreamSynchronize(e->stream);
+        }
+    }
+    if (s2 == ST_RUNNING) {
+        if (e->kind == ELLP_ENGINE_DUAL) launch_dleave(e);  // the three-launch loop starts from DevState::lr
+        return 1;
+    }
+    *result = status_message(*e->h_st, errbuf, errlen);
+    return 2;
+}
+
 ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen) {
     if (!e) return ELLP_ERR_ARG;
     if (errbuf && errlen) errbuf[0] = 0;
@@ -4549,11 +4684,17 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         e->hst_fresh = false;
         reconcile_counters(e);
         adopt_fin(e);
-        if (e->h_st->status != ST_RUNNING) {
+        const uint64_t iters0 = e->h_st->iters;
+        if (e->h_st->status == ST_NEED_EXACT && remaining > 0) {  // a guarded pivot closed the previous slice
+            const int tk = exact_takeover(e, remaining, &result, errbuf, errlen);
+            const uint64_t done0 = e->h_st->iters - iters0;
+            remaining = (tk == 2 || done0 >= max_iters) ? 0 : max_iters - done0;
+        } else if (e->h_st->status == ST_NEED_EXACT) {
+            remaining = 0;  // nothing to run: the status stays for the next slice
+        } else if (e->h_st->status != ST_RUNNING) {
             result = status_message(*e->h_st, errbuf, errlen);
             remaining = 0;
         }
-        const uint64_t iters0 = e->h_st->iters;
         const bool can_look_ahead = e->ill_tol <= 0.0 && !e->opts.profile;
         while (remaining > 0 && result == ELLP_MAXITER) {
             // Look-ahead polling (no tiny-pivot maintenance, no profiling, no follow-up refresh due):
@@ -4619,7 +4760,16 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 const uint64_t done = e->h_st->iters - iters0;
                 remaining = done < max_iters ? max_iters - done : 0;
                 if (service_maintenance_request(e)) continue;  // refreshed; the follow-up runs in the loop below
-                if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
+                if (e->h_st->status != ST_RUNNING) {
+                    const int tk = exact_takeover(e, remaining, &result, errbuf, errlen);
+                    if (tk == 1) {
+                        const uint64_t done2 = e->h_st->iters - iters0;
+                        remaining = done2 < max_iters ? max_iters - done2 : 0;
+                    } else if (tk == 0) {
+                        if (e->h_st->status == ST_NEED_EXACT) break;  // the slice is used up: the next one starts with the hand-over
+                        result = status_message(*e->h_st, errbuf, errlen);
+                    }
+                }
                 continue;
             }
             const bool chained = e->maint_chain > 0;
@@ -4645,7 +4795,16 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             if (chained) e->maint_chain = 0;
             if (service_maintenance_request(e)) continue;
             if (chained && e->h_st->status == ST_RUNNING) maintain_inverse(e, true);  // the follow-up refresh
-            if (e->h_st->status != ST_RUNNING) result = status_message(*e->h_st, errbuf, errlen);
+            if (e->h_st->status != ST_RUNNING) {
+                const int tk = exact_takeover(e, remaining, &result, errbuf, errlen);
+                if (tk == 1) {
+                    const uint64_t done2 = e->h_st->iters - iters0;
+                    remaining = done2 < max_iters ? max_iters - done2 : 0;
+                } else if (tk == 0) {
+                    if (e->h_st->status == ST_NEED_EXACT) break;  // the slice is used up: the next one starts with the hand-over
+                    result = status_message(*e->h_st, errbuf, errlen);
+                }
+            }
         }
     }
     // The caller's budget (ellp_opts.max_iter) is spent: the reference has run that many FULL loop bodies
@@ -4758,6 +4917,16 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                 if (cap >= 22) {
                     dst[20] = (double)e->rebuild_shortcuts;
                     dst[21] = e->t_setup;
+                    if (cap >= 28) {  // certified hybrid: on?, guarded pivots handed over, terminal statuses examined, of those not
+                                      // confirmed, loop bodies run by the exact kernel, rebuilds of B^-1 after a hand-over
+                        dst[22] = e->hybrid ? 1.0 : 0.0;
+                        dst[23] = (double)e->hy_guards;
+                        dst[24] = (double)e->hy_certs;
+                        dst[25] = (double)e->hy_disagree;
+                        dst[26] = (double)e->hy_exact_iters;
+                        dst[27] = (double)e->hy_rebuilds;
+                        return 28;
+                    }
                     return 22;
                 }
                 return 20;
@@ -4880,6 +5049,7 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
     }
     e->rank = rank;
     e->world = world;
+    if (world > 1) e->hybrid = false;  // certification is for unsharded engines
     e->nbs = (e->nblocks + world - 1) / world;
     e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     double *nx = static_cast<double *>(exchange_buffer);  // caller-owned (e.g. a torch tensor) ...
@@ -4925,6 +5095,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
     }
     HIPCHK(hipSetDevice(e->device));
     if (e->nN == 0) return ELLP_OPTIMAL;
+    e->hybrid = false;  // the stepped API drives the plain explicit-inverse engine (no guard: nobody would service its stop)
     if (e->small || !e->w_valid) {
         const ellp_status si = ensure_inverse(e, errbuf, errlen);
         if (si != ELLP_OPTIMAL) return si;
@@ -5377,6 +5548,7 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
                              !(getenv("ELLP_SHARD_SPLIT") && getenv("ELLP_SHARD_SPLIT")[0] == '1');
     const ellp_status s0 = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // rank, world, nbs, seg, X
     if (s0 != ELLP_OPTIMAL) return s0;
+    e->hybrid = false;  // certification is for unsharded engines
     if (keep_lagged) {
         e->lagged = true;
         e->lag_open = false;

@@ -260,7 +260,13 @@ class ShardedEngine:
         return status, stats, msg
 
     def read_point(self):
+        """the point of the replicated state; raises EllpHipError on any error code (Engine.read_point)"""
         return self.eng.read_point()
+
+    @property
+    def closing_status(self):
+        """what completing an open iteration produced at the last read_point (OPTIMAL: nothing; UNBOUNDED: the solve ended)"""
+        return getattr(self.eng, "closing_status", None)
 
     def close(self):
         if self.stream is not None:

@@ -61,6 +61,7 @@ enum { ELLP_NB_LOWER = 0, ELLP_NB_UPPER = 1, ELLP_NB_FREE = 2 };
 #define ELLP_FLAG_DENSE_PRICING 1      /* ellp_opts.flags */
 #define ELLP_FLAG_DUAL_MAX_VIOLATION 2 /* ellp_opts.flags */
 #define ELLP_FLAG_PRIMAL_STEEPEST_EDGE 4 /* ellp_opts.flags */
+#define ELLP_FLAG_NO_CERTIFY 8 /* ellp_opts.flags: the plain explicit-inverse engine where the default is the certified hybrid */
 
 typedef struct ellp_opts {
     uint64_t max_iter;       /* self.max_iter (primal…:16, dual…:17); default 1000 (:21) */
@@ -72,11 +73,15 @@ typedef struct ellp_opts {
     int32_t profile;         /* != 0: bracket every launch with HIP events (ellp_stats.kernel_ms) */
     int32_t use_graph;       /* reserved, must be 0 (hipGraph replay of the launch sequence is not implemented:
                                 on gfx950 the per-iteration cost is GPU-side dispatch, not host launches) */
-    int32_t pipeline;        /* launch structure of an iteration: 0 = engine default by size (m <= 128: 3; m >= 384: 2;
-                                otherwise 1), 1 = three launches (pricing | FTRAN | eta update), 2 = two bandwidth
+    int32_t pipeline;        /* launch structure of an iteration: 0 = engine default by size — m <= 128: 3; 128 < m <= 1024: the
+                                CERTIFIED HYBRID: 1 with a pivot guard, every terminal status and every guarded iteration
+                                re-examined by the LU-per-iteration kernel of 3 from the same arrays (DESIGN.md §3.1c;
+                                ELLP_FLAG_NO_CERTIFY: plain 1 / 2 by size); m > 1024: 2 —,
+                                1 = three launches (pricing | FTRAN | eta update), 2 = two bandwidth
                                 passes (primal: pricing | eta update of the previous pivot fused with this iteration's
                                 FTRAN; dual: pricing | FTRAN fused with this iteration's eta update, + a closing block),
-                                3 = the whole loop in one persistent workgroup with an LU per iteration (m <= 128) */
+                                3 = the whole loop in one persistent workgroup with an LU per iteration (m <= 1024: factors in
+                                LDS up to 128 rows, in global memory above) */
     int32_t trace_len;       /* > 0: keep the objective after each of the last `trace_len` iterations in a ring buffer on
                                 the device (ellp_engine_read_trace) — what the reference's `debug!("{iter} | {obj}")` line
                                 (primal…:161, dual…:189) prints; off by default, as the reference's logging is */
@@ -353,7 +358,10 @@ enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_T
                                                   cap >= 14: + drift, drift checks; cap >= 20: + maintenance requests
                                                   serviced, Newton-Schulz refreshes, rebuilds, x_B resyncs, last
                                                   refresh residual, launches per primal iteration;
-                                                  cap >= 22: + rebuilds settled by the permutation shortcut, setup seconds */ };
+                                                  cap >= 22: + rebuilds settled by the permutation shortcut, setup seconds;
+                                                  cap >= 28: + certified hybrid: on?, guarded pivots handed to the exact kernel,
+                                                  terminal statuses examined, of those not confirmed, loop bodies run by the
+                                                  exact kernel, rebuilds of B^-1 after a hand-over */ };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
 /* One Newton-Schulz step W <- W + W (I - A_B W) on the resident inverse (two f64 GEMMs); this

@@ -104,6 +104,49 @@ void eo_set_dual_rule(int bits) { g_dual_rule = bits; }
 static int g_primal_rule = 0;
 void eo_set_primal_rule(int rule) { g_primal_rule = rule; }
 
+/* Pivot guard of the CERTIFIED HYBRID (round 4; NOT the reference's behaviour — the policy of the engine's default above
+ * 128 rows, restated here so that it has a checker; off by default; eo_set_binv_guard).  The explicit-inverse loops
+ * (eo_*_binv_*) stop with EO_NEED_EXACT, BEFORE anything of the iteration is committed (x, the basis and the iteration
+ * counter stand as the previous iteration left them), when the pivot element they are about to use is suspicious:
+ *   |pivot| < abs   or   |pivot| < rel * max_i |column_i|      (column = B^-1 a_q)
+ * An explicit inverse is good to cond(A_B) * 2^-53; an entry of B^-1 a_q that is a structural zero comes out of it as
+ * ~1e-9 on the ill-conditioned bases of real LPs, passes the reference's |.| >= EPS test, wins a degenerate ratio test
+ * and makes the basis singular.  The caller then runs the LU-per-iteration loop (the reference's arithmetic, which keeps
+ * such entries at 0) for a few iterations from the same arrays and hands back. */
+static double g_guard_rel = 0.0, g_guard_abs = 0.0;
+void eo_set_binv_guard(double rel, double abs_) {
+    g_guard_rel = rel > 0.0 ? rel : 0.0;
+    g_guard_abs = abs_ > 0.0 ? abs_ : 0.0;
+}
+/* Second half of the certified hybrid's fast loop (eo_set_binv_zero_tol; 0 = off): an entry of B^-1 a_q, or of the dual's
+ * pricing row rho . a_j, whose modulus is below zero_tol is taken to BE zero — in the ratio tests and in the updates of
+ * x_B and d alike.  An explicit inverse is good to cond(A_B) * 2^-53; on the sparse bases of real LPs most entries of these
+ * vectors are structural zeros that come out of it as +-1e-9, and where the LU solves of the reference return exact zeros
+ * for them and leave x_B / d untouched, every pivot of the explicit-inverse loop adds theta * 1e-9 to each: the carried
+ * d drifts until a ratio test picks the wrong column and the phase ends at a basis that is dual infeasible by 1e-9
+ * (ADLITTLE x 18: 8 of 30 dual phase-1 runs).  A genuine entry below zero_tol would be refused as a pivot by the guard
+ * anyway (zero_tol < guard_abs). */
+static double g_zero_tol = 0.0;
+void eo_set_binv_zero_tol(double t) { g_zero_tol = t > 0.0 ? t : 0.0; }
+
+static int guard_trips(double pivot, const double *col, int64_t m) {
+    if (g_guard_rel <= 0.0 && g_guard_abs <= 0.0) return 0;
+    const double ap = fabs(pivot);
+    if (ap < g_guard_abs) return 1;
+    if (g_guard_rel > 0.0) {
+        double mx = 0.0;
+        for (int64_t i = 0; i < m; ++i)
+            if (fabs(col[i]) > mx) mx = fabs(col[i]);
+        if (ap < g_guard_rel * mx) return 1;
+    }
+    return 0;
+}
+
+/* certified hybrid: the dual loops are being CONTINUED from a point another loop of the same solve left (a hand-over in
+ * the middle of solve_with_initial), so the entry assertion on the initial point (dual…:139-151) does not apply */
+static int g_continuation = 0;
+void eo_set_continuation(int on) { g_continuation = on ? 1 : 0; }
+
 static int g_setup_threads = 1;
 void eo_set_setup_threads(int n) { g_setup_threads = n > 1 ? n : 1; }
 
@@ -1557,6 +1600,7 @@ int eo_primal_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const d
 #pragma omp parallel for schedule(static) num_threads(threads)
             for (int64_t i = 0; i < m; ++i) {
                 d[i] = sg * dot4(W + i * m, aq, m);
+                if (fabs(d[i]) < g_zero_tol) d[i] = 0.0;
             }
         }
         double lambda;
@@ -1614,6 +1658,11 @@ int eo_primal_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const d
         }
         if (isinf(lambda)) {
             status = EO_UNBOUNDED;
+            break;
+        }
+        if (new_basic >= 0 && guard_trips(d[new_basic], d, m)) { /* certified hybrid: nothing of this iteration is committed */
+            status = EO_NEED_EXACT;
+            entered -= 1;
             break;
         }
         if (lambda > 0.0) {
@@ -1694,7 +1743,7 @@ int eo_dual_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *
         int64_t k = 0;
         return solve_trivial(n_c, c, kind, lb, ub, x, N, Nb, &k, 1);
     }
-    for (int64_t j = 0; j < nN; ++j) { /* :139-151 */
+    for (int64_t j = 0; j < nN && !g_continuation; ++j) { /* :139-151 */
         double di = d[N[j]];
         int infeasible;
         if (Nb[j] == EO_NB_LOWER) infeasible = di < -EPS;
@@ -1960,7 +2009,7 @@ int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const dou
         set_err(err, errlen, "bad dimensions");
         return EO_ERR_BAD_DIMS;
     }
-    for (int64_t j = 0; j < nN; ++j) { /* :139-151 */
+    for (int64_t j = 0; j < nN && !g_continuation; ++j) { /* :139-151 */
         double di = d[N[j]];
         int infeasible;
         if (Nb[j] == EO_NB_LOWER) infeasible = di < -EPS;
@@ -2064,7 +2113,8 @@ int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const dou
         memcpy(rho, W + r * m, sizeof(double) * (size_t)m);
 #pragma omp parallel for schedule(static) num_threads(threads)
         for (int64_t j = 0; j < nN; ++j) {
-            const double dot = dot4(A_N + j * m, rho, m);
+            double dot = dot4(A_N + j * m, rho, m);
+            if (fabs(dot) < g_zero_tol) dot = 0.0;
             alpha[j] = (delta < 0.0) ? -dot : dot;
         }
         int64_t q = -1;
@@ -2109,7 +2159,15 @@ int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const dou
         {
             const double *aq = A_N + q * m;
 #pragma omp parallel for schedule(static) num_threads(threads)
-            for (int64_t i = 0; i < m; ++i) alpha_q[i] = dot4(W + i * m, aq, m);
+            for (int64_t i = 0; i < m; ++i) {
+                alpha_q[i] = dot4(W + i * m, aq, m);
+                if (fabs(alpha_q[i]) < g_zero_tol) alpha_q[i] = 0.0;
+            }
+        }
+        if (guard_trips(alpha_q[r], alpha_q, m)) { /* certified hybrid: nothing of this iteration is committed */
+            status = EO_NEED_EXACT;
+            entered -= 1;
+            break;
         }
         if (alpha_q[r] == 0.0) {
             set_err(err, errlen, "unwrap() on None in dual FTRAN");
@@ -2153,6 +2211,159 @@ done:
     if (iters_out) *iters_out = entered;
     free(A_B); free(A_N); free(W); free(rho); free(alpha); free(alpha_q);
     return status;
+}
+
+/* ------------------------------------------------------------------ the certified hybrid (round 4)
+ * NOT the reference's loop: the policy of the engine's default above 128 rows, restated here FIRST so that the device
+ * implementation has a checker (as every extension: partial pricing, the dual rules, steepest edge).
+ *
+ *   fast:    the explicit-inverse loop (eo_*_binv_*; the reference's pivoting rules on a maintained B^-1) with the pivot
+ *            guard on (eo_set_binv_guard: |pivot| < guard_abs stops it BEFORE the iteration is committed);
+ *   exact:   the reference's own loop, a fresh LU every iteration (eo_primal/dual_solve_with_initial), continued from
+ *            the arrays the fast loop left.
+ *
+ *   1. run fast until it stops;
+ *   2. EO_MAXITER -> return it; an error of the fast loop (singular / NaN / panic) is treated like a terminal status;
+ *   3. guard stop (EO_NEED_EXACT): run exact for up to K iterations (the suspicious iteration is its first one); a terminal
+ *      status of the exact loop is the result; otherwise back to 1;
+ *   4. terminal status S of fast (Optimal / Infeasible / Unbounded): run exact for up to K iterations.  If its FIRST
+ *      iteration ends with S the status is certified and returned (the loop body that found it is counted once, as in the
+ *      reference); if it ends otherwise, that is the result; if it pivots on, back to 1 with the counters advanced.
+ *   Dual only: before every hand-over to the exact loop x_B, y and d are recomputed from a fresh LU of the basis,
+ *   x_B = A_B^-1 (b - A_N x_N), y = A_B^-T c_B, d = c - A^T y — the leaving-row test (dual…:200-236) compares x_B with its
+ *   bounds to within EPS = 1e-10, the caller tests the phase objective, a sum over d, against EPS (dual…:45-50), and what
+ *   the inexact alpha of the fast loop has added to the carried vectors is far above that on ill-conditioned bases
+ *   (ADLITTLE x 18, 1,008 rows: 8 of 30 dual phase 1 runs ended "dual infeasible" on the carried d).  The primal keeps
+ *   the carried x: its exact zeros at degenerate vertices are worth more than a recomputation
+ *   that returns -3e-9 for them (measured: tools/hybrid_cpu.py, phase-1 objectives of -1e-8 and the reference's
+ *   assert!(obj > -EPS) after a resync; none without).
+ * Every decision that ends the solve is thus taken by the reference's arithmetic on a fresh factorisation
+ * (primal…:173-189,289-292,404-406; dual…:241-246,281-284). */
+static void hybrid_resync(int64_t m, int64_t n, const double *A, const double *c, const double *b, double *x, const int64_t *B,
+                          const int64_t *N, int64_t nN, double *y, double *d) {
+    double *A_B = (double *)xmalloc(sizeof(double) * (size_t)(m * m));
+    double *t = (double *)xmalloc(sizeof(double) * (size_t)m);
+    for (int64_t i = 0; i < m; ++i) memcpy(A_B + i * m, A + B[i] * m, sizeof(double) * (size_t)m);
+    for (int64_t i = 0; i < m; ++i) t[i] = b[i];
+    for (int64_t j = 0; j < nN; ++j) { /* t = b - A_N x_N, column by column in position order */
+        const double xj = x[N[j]];
+        if (xj == 0.0) continue;
+        const double *cj = A + N[j] * m;
+        for (int64_t i = 0; i < m; ++i) t[i] = t[i] - cj[i] * xj;
+    }
+    lu_t f;
+    lu_factor(&f, A_B, m, m);
+    if (lu_solve(&f, t)) { /* a singular basis keeps the carried vectors: the exact loop reports it */
+        for (int64_t i = 0; i < m; ++i) x[B[i]] = t[i];
+        for (int64_t i = 0; i < m; ++i) t[i] = c[B[i]];
+        if (getenv("EO_HYBRID_RESYNC_X_ONLY")) {
+        } else if (lu_btran(&f, t)) { /* y = A_B^-T c_B, d = c - A^T y (dual_problem.rs:162-172 at this basis) */
+            for (int64_t i = 0; i < m; ++i) y[i] = t[i];
+            for (int64_t j = 0; j < nN; ++j) {
+                const double *cj = A + N[j] * m;
+                double dot = 0.0;
+                for (int64_t i = 0; i < m; ++i) dot += cj[i] * y[i];
+                d[N[j]] = c[N[j]] - dot;
+            }
+            for (int64_t i = 0; i < m; ++i) d[B[i]] = 0.0;
+        }
+    }
+    (void)n;
+    lu_free(&f);
+    free(A_B);
+    free(t);
+}
+
+/* counters[0] hand-overs after a guard stop, [1] terminal statuses examined, [2] of those: not confirmed,
+ * [3] iterations done by the exact loop */
+static int hybrid_run(int dual, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c, const double *b,
+                      const uint8_t *kind, const double *lb, const double *ub, double *x, int64_t *B, int64_t nB,
+                      int64_t *N, uint8_t *Nb, int64_t nN, double *y, double *d, uint64_t max_iter, uint64_t *iters_out,
+                      int K, double guard_abs, int refresh, int threads, uint64_t *counters, char *err, size_t errlen) {
+    uint64_t total = 0;
+    int first = 1;
+    int status = EO_MAXITER;
+    const double save_rel = g_guard_rel, save_abs = g_guard_abs;
+    const int save_cont = g_continuation;
+    if (K < 1) K = 1;
+    if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0;
+    for (;;) {
+        if (total >= max_iter) {
+            status = EO_MAXITER;
+            break;
+        }
+        uint64_t it = 0;
+        int st;
+        g_guard_rel = 0.0;
+        g_guard_abs = guard_abs;
+        g_continuation = first ? save_cont : 1;
+        if (dual)
+            st = eo_dual_binv_solve_with_initial(m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, y, d, max_iter - total,
+                                                 &it, threads, refresh, NULL, err, errlen);
+        else
+            st = eo_primal_binv_solve_with_initial(m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, max_iter - total, &it,
+                                                   threads, refresh, NULL, err, errlen);
+        g_guard_rel = save_rel;
+        g_guard_abs = save_abs;
+        total += it;
+        if (first && (st == EO_ERR_BAD_DIMS || (st == EO_ERR_PANIC && it == 0 && dual))) { /* entry checks of the seam */
+            status = st;
+            break;
+        }
+        first = 0;
+        if (st == EO_MAXITER) {
+            status = st;
+            break;
+        }
+        const int guard_stop = st == EO_NEED_EXACT;
+        if (dual) hybrid_resync(m, n, A, c, b, x, B, N, nN, y, d);
+        uint64_t it2 = 0;
+        int st2;
+        uint64_t budget = max_iter - total;
+        /* the loop body in which the fast loop found its terminal status is examined again, not counted twice */
+        if (!guard_stop && total > 0) total -= 1, budget += 1;
+        if (budget > (uint64_t)K) budget = (uint64_t)K;
+        g_continuation = 1;
+        if (dual)
+            st2 = eo_dual_solve_with_initial(m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, y, d, budget, &it2, err, errlen);
+        else
+            st2 = eo_primal_solve_with_initial(m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, budget, &it2, err, errlen);
+        g_continuation = save_cont;
+        total += it2;
+        if (counters) {
+            counters[3] += it2;
+            if (guard_stop) counters[0] += 1;
+            else {
+                counters[1] += 1;
+                if (!(st2 == st && it2 <= 1)) counters[2] += 1;
+            }
+        }
+        if (st2 != EO_MAXITER) {
+            status = st2;
+            break;
+        }
+    }
+    g_continuation = save_cont;
+    if (iters_out) *iters_out = total;
+    return status;
+}
+
+int eo_primal_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                                        const double *b, const uint8_t *kind, const double *lb, const double *ub,
+                                        double *x, int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
+                                        uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
+                                        int threads, uint64_t *counters4, char *err, size_t errlen) {
+    return hybrid_run(0, m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, NULL, NULL, max_iter, iters, K, guard_abs,
+                      refresh, threads, counters4, err, errlen);
+}
+
+int eo_dual_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                                      const double *b, const uint8_t *kind, const double *lb, const double *ub, double *x,
+                                      int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y, double *d,
+                                      uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
+                                      int threads, uint64_t *counters4, char *err, size_t errlen) {
+    return hybrid_run(1, m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, y, d, max_iter, iters, K, guard_abs, refresh,
+                      threads, counters4, err, errlen);
 }
 
 /* ------------------------------------------------------------------ DualPhase1 / DualPhase2 */

@@ -40,6 +40,7 @@ enum {
     EO_INFEASIBLE = 1,
     EO_UNBOUNDED = 2,
     EO_MAXITER = 3,
+    EO_NEED_EXACT = 4,    /* eo_*_binv_* with eo_set_binv_guard: the pivot about to be used is suspicious (see ellp_oracle.c) */
     EO_ERR_BAD_DIMS = -1, /* EllPError "invalid B/N" */
     EO_ERR_SINGULAR = -2, /* EllPError "A_B is not invertible" */
     EO_ERR_NAN = -3,      /* panic "NaN detected" */
@@ -146,6 +147,22 @@ int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const dou
                                     double *d, uint64_t max_iter, uint64_t *iters, int threads,
                                     int refresh, double *loop_seconds, char *err, size_t errlen);
 
+/* The CERTIFIED HYBRID (round 4; not the reference's loop — the engine's default policy above 128 rows, restated; see
+ * ellp_oracle.c): the explicit-inverse loop with a pivot guard (|pivot| < guard_abs stops it before the iteration is
+ * committed), every terminal status and every guarded iteration handed to the LU-per-iteration loop for up to K iterations.
+ * counters4: [0] hand-overs after a guard stop, [1] terminal statuses examined, [2] of those not confirmed, [3] iterations
+ * of the exact loop. */
+int eo_primal_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                                        const double *b, const uint8_t *kind, const double *lb, const double *ub,
+                                        double *x, int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
+                                        uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
+                                        int threads, uint64_t *counters4, char *err, size_t errlen);
+int eo_dual_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
+                                      const double *b, const uint8_t *kind, const double *lb, const double *ub, double *x,
+                                      int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y, double *d,
+                                      uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
+                                      int threads, uint64_t *counters4, char *err, size_t errlen);
+
 /* Optional per-iteration trace for pivot-sequence parity (entering position, leaving
  * position or -1, objective). Set to NULL to disable.  Not thread-safe (test use only). */
 typedef void (*eo_trace_fn)(void *user, uint64_t iter, int64_t entering_pos,
@@ -162,6 +179,11 @@ void eo_set_setup_threads(int n);
 void eo_set_dual_rule(int bits);
 /* primal extension for eo_primal_solve_with_initial (see ellp_oracle.c): 1 = steepest-edge pricing; 0 = the reference's rule */
 void eo_set_primal_rule(int rule);
+/* pivot guard of the certified hybrid in the explicit-inverse loops (see ellp_oracle.c); 0, 0 = off */
+void eo_set_binv_guard(double rel, double abs_);
+void eo_set_continuation(int on);
+/* the explicit-inverse loops take entries of B^-1 a_q / rho . a_j below t to be zero (certified hybrid, see ellp_oracle.c); 0 = off */
+void eo_set_binv_zero_tol(double t);
 /* partial pricing for eo_primal_solve_with_initial (an extension, see ellp_oracle.c); P <= 1: off */
 void eo_set_partial_segments(int P);
 

@@ -16,6 +16,7 @@ KIND = {"Free": 0, "Lower": 1, "Upper": 2, "TwoSided": 3, "Fixed": 4}
 OP = {"Lte": 0, "Eq": 1, "Gte": 2}
 NB_LOWER, NB_UPPER, NB_FREE = 0, 1, 2
 OPTIMAL, INFEASIBLE, UNBOUNDED, MAXITER = 0, 1, 2, 3
+NEED_EXACT = 4  # the explicit-inverse loops under set_binv_guard: suspicious pivot, nothing committed
 ERR_BAD_DIMS, ERR_SINGULAR, ERR_NAN, ERR_ARG, ERR_PANIC = -1, -2, -3, -5, -6
 MAX_ITER_NONE = 2**64 - 1
 STATUS_NAME = {0: "optimal", 1: "infeasible", 2: "unbounded", 3: "maxiter"}
@@ -105,6 +106,11 @@ def lib():
     L.eo_primal_binv_solve_with_initial.restype = C.c_int
     L.eo_primal_binv_solve_with_initial.argtypes = common + [
         C.c_uint64, C.POINTER(C.c_uint64), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+    hy_tail = [C.c_uint64, C.POINTER(C.c_uint64), C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.eo_primal_hybrid_solve_with_initial.restype = C.c_int
+    L.eo_primal_hybrid_solve_with_initial.argtypes = common + hy_tail
+    L.eo_dual_hybrid_solve_with_initial.restype = C.c_int
+    L.eo_dual_hybrid_solve_with_initial.argtypes = common + [C.c_void_p, C.c_void_p] + hy_tail
     L.eo_solve.restype = C.c_int
     L.eo_solve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.POINTER(_Result)]
     L.eo_result_free.argtypes = [C.POINTER(_Result)]
@@ -113,6 +119,9 @@ def lib():
     L.eo_set_partial_segments.argtypes = [C.c_int]
     L.eo_set_dual_rule.argtypes = [C.c_int]
     L.eo_set_primal_rule.argtypes = [C.c_int]
+    L.eo_set_binv_guard.argtypes = [C.c_double, C.c_double]
+    L.eo_set_continuation.argtypes = [C.c_int]
+    L.eo_set_binv_zero_tol.argtypes = [C.c_double]
     L.eo_synth_dense_lp.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
     _lib = L
@@ -346,6 +355,36 @@ def dual_solve_with_initial(ph, max_iter=MAX_ITER_NONE):
     return st, it.value, err.value.decode()
 
 
+HYBRID_K = 8            # exact iterations per hand-over
+HYBRID_GUARD_ABS = 1e-7  # a pivot below this is not taken by the explicit-inverse loop
+
+
+def primal_hybrid_solve_with_initial(ph, max_iter=MAX_ITER_NONE, K=HYBRID_K, guard_abs=HYBRID_GUARD_ABS, refresh=64, threads=1):
+    """The certified hybrid (the engine's default policy above 128 rows, restated in ellp_oracle.c), primal, in place on a
+    Phase view.  Returns (status, iters, err, counters) with counters = [guard hand-overs, terminal statuses examined,
+    not confirmed, exact iterations]."""
+    it = C.c_uint64(0)
+    err = C.create_string_buffer(256)
+    cnt = np.zeros(4, dtype=np.uint64)
+    st = lib().eo_primal_hybrid_solve_with_initial(
+        ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
+        _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
+        max_iter, C.byref(it), int(K), float(guard_abs), int(refresh), int(threads), _ptr(cnt), err, 256)
+    return st, it.value, err.value.decode(), [int(v) for v in cnt]
+
+
+def dual_hybrid_solve_with_initial(ph, max_iter=MAX_ITER_NONE, K=HYBRID_K, guard_abs=HYBRID_GUARD_ABS, refresh=64, threads=1):
+    """The certified hybrid, dual.  Returns (status, iters, err, counters)."""
+    it = C.c_uint64(0)
+    err = C.create_string_buffer(256)
+    cnt = np.zeros(4, dtype=np.uint64)
+    st = lib().eo_dual_hybrid_solve_with_initial(
+        ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
+        _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
+        _ptr(ph.y), _ptr(ph.d), max_iter, C.byref(it), int(K), float(guard_abs), int(refresh), int(threads), _ptr(cnt), err, 256)
+    return st, it.value, err.value.decode(), [int(v) for v in cnt]
+
+
 class Result:
     def __init__(self, r):
         self.status = r.status
@@ -398,6 +437,22 @@ def set_dual_rule(bits):
 def set_primal_rule(rule):
     """primal extension in primal_solve_with_initial (not the reference's rule; see ellp_oracle.c): 1 steepest-edge pricing"""
     lib().eo_set_primal_rule(int(rule))
+
+
+def set_binv_guard(rel, abs_=0.0):
+    """pivot guard of the certified hybrid in the explicit-inverse loops (an extension, see ellp_oracle.c): they stop with
+    NEED_EXACT before committing an iteration whose pivot is below abs_ or below rel * max|B^-1 a_q|; 0, 0 = off"""
+    lib().eo_set_binv_guard(float(rel), float(abs_))
+
+
+def set_binv_zero_tol(t):
+    """the explicit-inverse loops take entries of B^-1 a_q and of the dual pricing row below t to be zero (certified hybrid)"""
+    lib().eo_set_binv_zero_tol(float(t))
+
+
+def set_continuation(on):
+    """the dual loops skip their entry assertion (dual…:139-151): the call continues a solve another loop began"""
+    lib().eo_set_continuation(1 if on else 0)
 
 
 def set_partial_segments(P):

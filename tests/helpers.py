@@ -153,3 +153,28 @@ def permuted_fixture(fx, rng):
     rows = [fx["constraints"][i] for i in rng.permutation(len(fx["constraints"]))]
     return {"vars": [fx["vars"][j] for j in perm],
             "constraints": [[[[int(inv[j]), a] for j, a in coeffs], op, rhs] for coeffs, op, rhs in rows]}
+
+
+def fixture_violation(fx, x):
+    """Largest violation of a fixture's constraints (relative to 1 + |rhs|) and of its variable bounds (absolute) at the
+    point x — what Problem::is_feasible (src/problem.rs:108-154, :237-250) tests with the absolute EPS = 1e-10, as a
+    number, so that a test can state its own tolerance."""
+    worst_c, worst_b = 0.0, 0.0
+    for coeffs, op, rhs in fx["constraints"]:
+        lhs = sum(a * x[j] for j, a in coeffs)
+        if op == "Lte":
+            v = lhs - rhs
+        elif op == "Gte":
+            v = rhs - lhs
+        else:
+            v = abs(lhs - rhs)
+        worst_c = max(worst_c, v / (1.0 + abs(rhs)))
+    for j, (obj, (kind, lb, ub)) in enumerate(fx["vars"]):
+        if kind in ("Lower", "TwoSided"):
+            worst_b = max(worst_b, lb - x[j])
+        if kind in ("Upper", "TwoSided"):
+            worst_b = max(worst_b, x[j] - ub)
+        if kind == "Fixed":
+            worst_b = max(worst_b, abs(x[j] - lb))
+    return worst_c, worst_b
+

@@ -60,6 +60,14 @@ def assert_same_point(ov, fp, st_o, st_g, it_o, stats, exact_basis=True):
         # else: a degenerate optimum may be reached with a different (equally optimal) basis
 
 
+def reached_device(out):
+    """the fixtures whose set-up already decides them (infeasible by construction, no constraint row left) never call the
+    seam: nothing on the device is exercised, so the test is SKIPPED for them, not passed"""
+    if out in ("infeasible-by-setup", "trivial"):
+        pytest.skip(f"{out}: the solve never reaches solve_with_initial (no device code runs)")
+    return out
+
+
 def primal_two_phase(fx, exact_basis=True, **optkw):
     """Mirrors PrimalSimplexSolver::solve (primal…:32-93) with the GPU loop checked against the
     oracle loop phase by phase on identical inputs."""
@@ -86,8 +94,9 @@ def primal_two_phase(fx, exact_basis=True, **optkw):
 
 @pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
 def test_primal_known_answers(fx):
-    out = primal_two_phase(fx, refactor_period=1 << 30)
-    if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj"):
+    out = reached_device(primal_two_phase(fx, refactor_period=1 << 30))
+    if fx["check"] in ("optimal", "optimal_obj"):
+        assert isinstance(out, tuple), out
         status, fp2 = out
         assert status == "optimal"
         assert abs(fp2.obj() - fx["obj"]) < 1e-8
@@ -102,8 +111,9 @@ def test_primal_known_answers_default_maintenance(fx, pipeline):
     this size the persistent exact kernel), and on the explicit-inverse engine with its DEFAULT
     maintenance (pipeline 1: Newton-Schulz refresh every 16 iterations at this size, reactive
     maintenance after tiny pivots, x_B re-checked against the fresh inverse)."""
-    out = primal_two_phase(fx, pipeline=pipeline)
-    if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj"):
+    out = reached_device(primal_two_phase(fx, pipeline=pipeline))
+    if fx["check"] in ("optimal", "optimal_obj"):
+        assert isinstance(out, tuple), out
         status, fp2 = out
         assert status == "optimal"
         assert abs(fp2.obj() - fx["obj"]) < 1e-8
@@ -170,7 +180,7 @@ def dual_two_phase(fx, exact_basis=True, **optkw):
 
 @pytest.mark.parametrize("fx", KA["problems"], ids=[p["name"] for p in KA["problems"]])
 def test_dual_known_answers(fx):
-    out = dual_two_phase(fx, refactor_period=1 << 30)
+    out = reached_device(dual_two_phase(fx, refactor_period=1 << 30))
     if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj") and out[0] == "optimal":
         status, fp2 = out
         assert abs(fp2.obj() - fx["obj"]) < 1e-8
@@ -183,7 +193,7 @@ def test_dual_known_answers(fx):
 def test_dual_known_answers_default_maintenance(fx, pipeline):
     """The 25 fixtures through the dual loop, pivot for pivot: the default path and the
     explicit-inverse engine with its default maintenance."""
-    out = dual_two_phase(fx, pipeline=pipeline)
+    out = reached_device(dual_two_phase(fx, pipeline=pipeline))
     if isinstance(out, tuple) and fx["check"] in ("optimal", "optimal_obj") and out[0] == "optimal":
         status, fp2 = out
         assert abs(fp2.obj() - fx["obj"]) < 1e-8

@@ -1,0 +1,235 @@
+"""The certified hybrid — the engine's default for 128 < m <= 1024 (the policy restated in
+oracle/ellp_oracle.c, hybrid_run): the explicit-inverse loop with a pivot guard, every terminal status and every
+guarded iteration re-examined by the LU-per-iteration kernel from the same arrays.
+
+Fixtures: block-diagonal replications of the reference's netlib LPs in random variable / constraint orders (the
+reference builds its problems by iterating HashMaps, tests/problems/mod.rs:657-674, so every order occurs).  Real,
+sparse, degenerate, ill-conditioned — the LPs on which the plain explicit-inverse loop ends wrongly on 10-40 % of the
+orders (tools/blockdiag_cpu.py).  Parity is on RESULTS, as the reference's own tests pin them: status,
+objective against the pinned optimum (tests/problems/mod.rs:661,667,673 x the number of copies, relative 1e-9) and
+feasibility of the point.  How the ORACLE (the reference's LU-per-iteration loop) ends on each of these orders is
+committed in tests/golden/blockdiag_orders.json / blockdiag_large.json (made by tests/campaign/blockdiag_large_golden.py;
+minutes per solve above 512 rows): an order on which the reference's own loop fails is the only kind on which the engine
+may fail too."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, blockdiag, fixture_violation, known_answers, permuted_fixture, read_mps
+from oracle import ellp_oracle as eo
+from test_gpu_small import flat
+
+pytestmark = pytest.mark.gpu
+
+# (name, copies, orders): at the seam, phase by phase, from the oracle's arrays
+SEAM_CASES = [("adlittle", 3, 60), ("blend", 2, 60), ("adlittle", 6, 60), ("adlittle", 10, 30)]
+# through the user API (host mirror: standard form with the rank check on the device, both phases on one resident engine)
+API_CASES = [("adlittle", 10, 30), ("adlittle", 18, 30)]
+
+
+def _E():
+    from ellp_amd import _engine as E
+    return E
+
+
+def _golden():
+    out = {}
+    for f in ("blockdiag_orders.json", "blockdiag_large.json"):
+        p = os.path.join(GOLDEN, f)
+        if os.path.exists(p):
+            out.update(json.load(open(p)))
+    return out
+
+
+def oracle_reached_optimum(gold, key, solver, trial, want):
+    """True / False from the committed outcome of the LU-per-iteration oracle, None if it is not on file"""
+    rec = gold.get(key, {}).get(f"{solver}:lu", {}).get(str(trial))
+    if rec is None:
+        return None
+    stage, st, obj, its = rec[:4]
+    return stage in ("p2", "d2") and st == eo.OPTIMAL and obj is not None and abs(obj / want - 1.0) < 1e-9
+
+
+def feasibility(v, x):
+    """max violation of A x = b (relative to 1 + |b|) and of the bounds, for a standard-form view and a point"""
+    A = v.A_matrix()
+    r = np.abs(A @ x[:v.n] - v.b) / (1.0 + np.abs(v.b))
+    lo = np.where(np.isin(v.kind, (1, 3, 4)), v.lb - x, -np.inf)
+    hi = np.where(np.isin(v.kind, (2, 3)), x - v.ub, -np.inf)
+    hi = np.where(v.kind == 4, np.abs(x - v.lb), hi)
+    return float(r.max()), float(max(lo.max(), hi.max(), 0.0))
+
+
+def run_phase(view, which, tally, max_iter=2000000):
+    """one solve_with_initial at the seam through a default-options engine; the point goes back into `view`"""
+    E = _E()
+    fp = flat(view)
+    eng = E.Engine(E.ENGINE_PRIMAL if which == "primal" else E.ENGINE_DUAL, fp, E.default_opts(max_iter=max_iter))
+    try:
+        c0 = eng.counters()
+        assert c0["hybrid"], "the default engine at this size must be the certified hybrid"
+        st, stats, msg = eng.run(max_iter)
+        eng.read_point()
+        c = eng.counters()
+    finally:
+        eng.close()
+    for k in ("hybrid_guards", "hybrid_certs", "hybrid_disagreed", "hybrid_exact_iters"):
+        tally[k] = tally.get(k, 0) + c[k]
+    tally["iters"] = tally.get("iters", 0) + int(stats.iters)
+    view.x[:] = fp.x
+    view.B[:] = fp.B
+    view.N[:view.nN] = fp.N[:view.nN]
+    view.Nb[:view.nN] = fp.Nb[:view.nN]
+    if which == "dual":
+        view.y[:] = fp.y
+        view.d[:] = fp.d
+    return st, msg
+
+
+def seam_order(fx, want, tally):
+    """both solvers on one order, as the reference's solve() drives the seam (primal…:32-93, dual…:33-108);
+    returns {solver: (reached the pinned optimum, what happened)}"""
+    prob = eo.Problem.from_fixture(fx)
+    out = {}
+    p1, err = eo.primal_phase1(prob)
+    assert p1 is not None and not err
+    v = p1.view()
+    st, msg = run_phase(v, "primal", tally)
+    ok, what = False, ("p1", st, v.obj(), msg)
+    if st == eo.OPTIMAL and -1e-10 < v.obj() < 1e-10:  # primal…:42-50
+        p1.store_point(v)
+        v2 = eo.primal_phase2(p1).view()
+        st2, msg2 = run_phase(v2, "primal", tally)
+        res, bnd = feasibility(v2, v2.x)
+        ok = st2 == eo.OPTIMAL and abs(v2.obj() / want - 1.0) < 1e-9 and res < 1e-8 and bnd < 1e-8
+        what = ("p2", st2, v2.obj(), res, bnd, msg2)
+    out["primal"] = (ok, what)
+    d1, err = eo.dual_phase1(prob)
+    assert d1 is not None and not err
+    v = d1.view()
+    st, msg = run_phase(v, "dual", tally)
+    ok, what = False, ("d1", st, msg)
+    if st == eo.OPTIMAL:
+        d1.store_point(v)
+        d2, err2 = eo.dual_phase2(d1)
+        what = ("d2-setup", err2)
+        if d2 is not None and not err2:
+            v2 = d2.view()
+            st2, msg2 = run_phase(v2, "dual", tally)
+            res, bnd = feasibility(v2, v2.x)
+            ok = st2 == eo.OPTIMAL and abs(v2.obj() / want - 1.0) < 1e-9 and res < 1e-8 and bnd < 1e-8
+            what = ("d2", st2, v2.obj(), res, bnd, msg2)
+    out["dual"] = (ok, what)
+    return out
+
+
+def _orders(name, copies, orders):
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == name)
+    base = blockdiag(read_mps(os.path.join(GOLDEN, ka["file"])), copies)
+    rng = np.random.default_rng(zlib.crc32(f"{name}x{copies}".encode()))
+    for trial in range(orders):
+        yield trial, permuted_fixture(base, rng), copies * ka["obj"]
+
+
+@pytest.mark.parametrize("name,copies,orders", SEAM_CASES, ids=[f"{n}x{c}" for n, c, _ in SEAM_CASES])
+def test_every_order_reaches_the_pinned_optimum_at_the_seam(name, copies, orders):
+    gold = _golden()
+    key = f"{name}x{copies}"
+    tally, bad, excused = {}, [], []
+    for trial, fx, want in _orders(name, copies, orders):
+        res = seam_order(fx, want, tally)
+        for solver, (ok, what) in res.items():
+            if ok:
+                continue
+            ref = oracle_reached_optimum(gold, key, solver, trial, want)
+            # excused: the reference's own loop fails on this order too, or the reference's DualPhase2::from trips one of
+            # its absolute-EPS assertions on the sign of d (dual_problem.rs:293-310) at the phase-1 basis — a basis the
+            # exact kernel has certified optimal for phase 1; the reference meets the same panic on other orders
+            # (tests/golden: "d2-setup")
+            setup = what[0] == "d2-setup"
+            (excused if (ref is False or setup) else bad).append((trial, solver, what, ref))
+    print(f"{key}: {orders} orders x 2 solvers; hybrid counters {tally}; reference-rule failures: {excused}")
+    assert not bad, bad
+    assert len(excused) <= max(2, orders // 10), excused
+
+
+@pytest.mark.parametrize("name,copies,orders", API_CASES, ids=[f"{n}x{c}" for n, c, _ in API_CASES])
+def test_every_order_through_the_user_api(name, copies, orders):
+    """Problem -> PrimalSimplexSolver / DualSimplexSolver ::new(None).solve, default engine options"""
+    import ellp_amd
+    gold = _golden()
+    key = f"{name}x{copies}"
+    bad, excused = [], []
+    for trial, fx, want in _orders(name, copies, orders):
+        prob = ellp_amd.Problem.from_fixture(fx)
+        for solver, cls in (("primal", ellp_amd.PrimalSimplexSolver), ("dual", ellp_amd.DualSimplexSolver)):
+            what = None
+            try:
+                r = cls.new(None).solve(prob.clone())
+                ok = r.kind == ellp_amd.SolverResult.Optimal and abs(r.solution.obj() / want - 1.0) < 1e-9
+                viol = fixture_violation(fx, r.solution.x()) if ok else None
+                ok = ok and viol[0] < 1e-8 and viol[1] < 1e-8  # rows relative to 1 + |rhs|, bounds absolute
+                what = (r.kind, r.solution.obj() if r.solution else None, r.iters, viol)
+            except (RuntimeError, ellp_amd.EllPError) as ex:  # the reference's panics / Err(EllPError) surface as exceptions
+                ok, what = False, repr(ex)
+            if not ok:
+                ref = oracle_reached_optimum(gold, key, solver, trial, want)
+                (excused if ref is False else bad).append((trial, solver, what, ref))
+    print(f"{key} through the user API: {orders} orders x 2 solvers; reference-rule failures shared: {excused}")
+    assert not bad, bad
+    assert len(excused) <= max(2, orders // 6), excused
+
+
+def test_guarded_pivot_hands_over_and_back():
+    """a guard far above its default (every pivot below 1e-2 is refused) on ADLITTLE x 3: many hand-overs, slices that end on
+    a refused pivot, the same optimum"""
+    E = _E()
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == "adlittle")
+    want = 3 * ka["obj"]
+    trial, fx, _ = next(_orders("adlittle", 3, 1))
+    prob = eo.Problem.from_fixture(fx)
+    os.environ["ELLP_GUARD_ABS"] = "1e-2"
+    try:
+        p1, err = eo.primal_phase1(prob)
+        v = p1.view()
+        fp = flat(v)
+        eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+    finally:
+        del os.environ["ELLP_GUARD_ABS"]
+    try:
+        st = E.MAXITER
+        slices = 0
+        while st == E.MAXITER and slices < 100000:
+            st, stats, msg = eng.run(7)  # short slices: a refused pivot often closes one
+            slices += 1
+        eng.read_point()
+        c = eng.counters()
+    finally:
+        eng.close()
+    assert st == E.OPTIMAL, (st, msg)
+    assert c["hybrid_guards"] > 0 and c["hybrid_certs"] >= 1, c
+    v.x[:] = fp.x
+    assert -1e-10 < v.obj() < 1e-10, v.obj()
+    v.B[:] = fp.B
+    v.N[:v.nN] = fp.N[:v.nN]
+    v.Nb[:v.nN] = fp.Nb[:v.nN]
+    p1.store_point(v)
+    v2 = eo.primal_phase2(p1).view()
+    tally = {}
+    st2, msg2 = run_phase(v2, "primal", tally)
+    assert st2 == E.OPTIMAL and abs(v2.obj() / want - 1.0) < 1e-9, (st2, v2.obj(), want)
+
+
+def test_flag_no_certify_is_the_plain_engine():
+    E = _E()
+    trial, fx, _ = next(_orders("adlittle", 3, 1))
+    p1, err = eo.primal_phase1(eo.Problem.from_fixture(fx))
+    fp = flat(p1.view())
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, flags=8))
+    try:
+        assert not eng.counters()["hybrid"]
+    finally:
+        eng.close()

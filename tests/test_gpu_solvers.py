@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from ellp_amd import DualSimplexSolver, PrimalSimplexSolver, Problem, parse_mps
-from helpers import GOLDEN, check_result, known_answers
+from helpers import GOLDEN, check_result, fixture_violation, known_answers, read_mps
 
 pytestmark = pytest.mark.gpu
 KA = known_answers()
@@ -31,7 +31,10 @@ def test_benchmarks(fx, solver):
     result = SOLVERS[solver].default().solve(prob)
     assert result.kind == "optimal", result
     check_result(fx, result.kind, result.solution.obj(), result.solution.x(), KA["abs_eps"], KA["rel_eps"])
-    assert prob.is_feasible(result.solution.x()) or True  # feasibility uses EPS=1e-10; informational
+    # Problem::is_feasible tests with the ABSOLUTE EPS = 1e-10 (src/problem.rs:108-154), which no solver meets on rows with
+    # right-hand sides of 1e3; the same test with a stated tolerance: rows relative to 1 + |rhs|, bounds absolute
+    rows, bounds = fixture_violation(read_mps(os.path.join(GOLDEN, fx["file"])), result.solution.x())
+    assert rows < 1e-9 and bounds < 1e-9, (rows, bounds)
 
 
 @pytest.mark.parametrize("solver", ["primal", "dual"])
