@@ -179,11 +179,37 @@ class Ctx:
         return all(int(p.item()) == value for p in parts)
 
 
-def pmc_traffic(m, n, solver, dual):
-    """HBM traffic of the pricing kernel per launch, from the committed PMC passes (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 x2 read correction; tools/pmc_traffic.sh).  It is
-    read from profiles/, not measured in this run: the file it came from is named beside it."""
+def _engine_hash():
+    from ellp_amd.build import engine_source_hash
+    return engine_source_hash()
+
+
+def _kernel_matches(kname, which, dual):
+    """which = 'pricing' | 'dominant' (the pass over B^-1: FTRAN fused with the eta update)"""
+    mode = "1" if dual else "0"
+    if which == "dominant":
+        if dual:
+            return kname.startswith("k_dual_fu<")
+        return kname.startswith("k_ftran_eta<") and not kname.rstrip(">").endswith("true")
+    if kname.startswith("k_price2_wave") or kname.startswith("k_price2<"):  # two-launch pipeline: primal only
+        if kname.rstrip(">").endswith("true") and kname.startswith("k_price2_wave"):
+            return False  # the column-sharded instantiation
+        return not dual
+    if kname.startswith("k_price_wave<"):
+        return kname[len("k_price_wave<"):].rstrip(">").strip() == mode
+    if kname.startswith("k_price<"):
+        return kname.split(",")[1].strip().rstrip(">") == mode
+    return False
+
+
+def pmc_traffic(m, n, solver, dual, which="pricing"):
+    """HBM traffic of a kernel per launch, from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs, gfx950 x2 read correction; tools/pmc_traffic.sh).  Read from profiles/, not measured in this run: the
+    file it came from is named beside it, and a file that was measured on OTHER kernels than the ones this run executes
+    (its engine_source_hash differs from the sources') is refused — returns (None, why)."""
     import glob
+    want = _engine_hash()
+    stale = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
             pm = json.load(open(f))
@@ -191,30 +217,27 @@ def pmc_traffic(m, n, solver, dual):
             continue
         if pm.get("workload") != f"m={m} n={n} {solver}":
             continue
-        mode = "1" if dual else "0"
+        if pm.get("engine_source_hash") != want:
+            stale = stale or os.path.relpath(f, ROOT)
+            continue
         for kname, kv in pm["kernels"].items():
-            hit = False
-            if kname.startswith("k_price2_wave") or kname.startswith("k_price2<"):  # two-launch pipeline: primal only
-                if kname.rstrip(">").endswith("true") and kname.startswith("k_price2_wave"):
-                    continue  # the column-sharded instantiation
-                hit = not dual
-            elif kname.startswith("k_price_wave<"):
-                hit = kname[len("k_price_wave<"):].rstrip(">").strip() == mode
-            elif kname.startswith("k_price<"):
-                hit = kname.split(",")[1].strip().rstrip(">") == mode
-            if hit:
+            if _kernel_matches(kname, which, dual):
                 return kv["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)
-    return None, None
+    return None, (f"no PMC file for the current engine sources ({want}); newest older one: {stale}" if stale else None)
 
 
-def rocprof_avg_us(kernel_prefixes):
-    """average duration of the dominant kernel in the newest committed rocprofv3 --kernel-trace --stats summary of
-    this command (profiles/*default_kernel_stats.csv), with the file it came from — so that roofline.frac can be
-    recomputed from the line alone"""
+def rocprof_avg_us(which, dual):
+    """average duration of a kernel in a committed rocprofv3 --kernel-trace --stats summary of this command
+    (profiles/*default_kernel_stats.csv) — only from a summary whose side file (.meta.json, tools/rocprof_bench.sh) says
+    it was taken on the current engine sources"""
     import csv
     import glob
+    want = _engine_hash()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*default_kernel_stats.csv")), reverse=True):
+        meta = f[:-4] + ".meta.json"
         try:
+            if json.load(open(meta)).get("engine_source_hash") != want:
+                continue
             rows = list(csv.DictReader(open(f)))
         except Exception:
             continue
@@ -222,7 +245,7 @@ def rocprof_avg_us(kernel_prefixes):
             name = row.get("Name") or row.get("KernelName") or ""
             mm = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", name)
             short = mm.group(1) if mm else ""
-            if any(short.startswith(px) for px in kernel_prefixes):
+            if short and _kernel_matches(short, which, dual):
                 try:
                     avg_ns = float(row.get("AverageNs") or row.get("Average") or 0.0)
                 except ValueError:
@@ -370,6 +393,7 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
 
 
 def roofline_of(meas, m, n, solver, world):
+    """roofline of the pricing pass (SURVEY.md §8d's headline kernel); roofline_dominant(): the pass over B^-1"""
     dual = solver == "dual"
     pk = "dprice" if dual else "price"
     prof = meas["prof"]
@@ -380,26 +404,55 @@ def roofline_of(meas, m, n, solver, world):
         traffic, src = pmc_traffic(m, n, solver, dual)
     t_us = prof[pk]["avg_us"]
     ach = meas["price_bytes"] / (t_us * 1e-6) / 1e9
-    rp_us, rp_name, rp_file = (None, None, None)
-    if world == 1 and (m, n) == (2000, 5000) and not dual:
-        rp_us, rp_name, rp_file = rocprof_avg_us(["k_price2_wave"])
+    rp_us, rp_name, rp_file = rocprof_avg_us("pricing", dual) if (world == 1 and (m, n) in ((2000, 5000), (4000, 40000))) else (None, None, None)
+    if rp_name is not None and (m, n) == (4000, 40000) and not rp_name.startswith("k_price2<"):
+        rp_us, rp_name, rp_file = (None, None, None)  # the summary of the default command holds config 3's wave kernel under the same prefix
     return {"kernel": "pricing pass of one GPU (k_price*<%d>)" % (1 if dual else 0), "bound": "hbm",
-            "avg_us_rocprof": rp_us, "avg_us_rocprof_kernel": rp_name,
-            "avg_us_rocprof_source": (rp_file + " (rocprofv3 --kernel-trace --stats of an earlier run of this command)") if rp_file else None,
-            "frac_rocprof": round(meas["price_bytes"] / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp_us else None,
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_source": (src + " (rocprofv3 --pmc passes of an earlier run of this "
-                                                   "command, not measured in this run)") if src else None,
+            "traffic": traffic,
+            "traffic_source": (src + " (rocprofv3 --pmc passes of an earlier run of this command on the same engine sources, "
+                                     "not measured in this run)") if traffic else src,
+            "frac_traffic": round(traffic / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "avg_us_rocprof": rp_us, "avg_us_rocprof_kernel": rp_name,
+            "avg_us_rocprof_source": (rp_file + " (rocprofv3 --kernel-trace --stats of an earlier run of this command on the same engine sources)") if rp_file else None,
             "frac_of_measured_achievable": round(ach / 6290.0, 4),
-            "note": "achieved = ALGORITHMIC bytes of the pass (SURVEY.md §8d: 8 m |N|, every nonbasic column once) / its "
-                    "duration.  The kernel streams fewer: unit columns (slacks, artificials: a third of config 3's nonbasic "
-                    "columns) are priced from their single entry, so `traffic` (PMC) is BELOW bytes_per_launch and `achieved` can "
-                    "exceed what HBM delivered; ellp_opts.flags = 1 streams everything (tools/unit_columns_ab.py has both).  "
-                    "peak = the 8 TB/s spec; /opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s as achievable by a pure "
-                    "streaming read.  The primal kernel's duration includes the ratio-test fold of the previous iteration in "
-                    "its prologue (two-launch pipeline), about 2.5 us before the first column is read.",
+            "note": "achieved / frac = ALGORITHMIC bytes of the pass (SURVEY.md §8d: 8 m |N|, every nonbasic column once) / its "
+                    "duration — the contract's definition, NOT an HBM-utilisation figure: the kernel streams fewer bytes (unit "
+                    "columns — slacks, artificials: a third of config 3's nonbasic columns — are priced from their single entry; "
+                    "ellp_opts.flags = 1 streams everything, tools/unit_columns_ab.py has both).  frac_traffic = the bytes HBM "
+                    "really delivered (`traffic`, PMC) / duration / peak is the utilisation.  peak = the 8 TB/s spec; "
+                    "/opt/skills/guides/MI355X_MICROARCH.md measures 6.29 TB/s as achievable by a pure streaming read.  The primal "
+                    "kernel's duration includes the ratio-test fold of the previous iteration in its prologue (two-launch "
+                    "pipeline), about 2.5 us before the first column is read.",
             "bytes_per_launch": meas["price_bytes"], "avg_us": round(t_us, 3),
             "avg_us_raw": round(t_us + prof.get("event_cost", {}).get("avg_us", 0.0), 3), "timing": EVENT_NOTE}
+
+
+def roofline_dominant(meas, m, n, solver, world):
+    """the pass over B^-1 — FTRAN fused with the eta update (k_ftran_eta / k_dual_fu): the longer of the two launches of
+    an iteration at config 3 / 4.  SURVEY §8d bytes: FTRAN 8 m^2 + update 16 m^2; moved: one read + one write of B^-1."""
+    dual = solver == "dual"
+    prof = meas["prof"]
+    if "ftran" not in prof or m < 384:
+        return None
+    ld = (m + 15) // 16 * 16
+    t_us = prof["ftran"]["avg_us"]
+    alg, moved = 24.0 * m * ld, 16.0 * m * ld
+    traffic, src = pmc_traffic(m, n, solver, dual, "dominant") if world == 1 else (None, None)
+    rp_us, rp_name, rp_file = rocprof_avg_us("dominant", dual) if world == 1 else (None, None, None)
+    if rp_name is not None and (("<8" in rp_name) != (m > 2048)):
+        rp_us, rp_name, rp_file = (None, None, None)  # the other configuration's instantiation
+    ach = alg / (t_us * 1e-6) / 1e9
+    return {"kernel": "k_dual_fu (FTRAN + eta update + x_B / d / y updates)" if dual else "k_ftran_eta (eta update of the previous pivot + FTRAN)",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "bytes_per_launch": alg, "bytes_moved_per_launch": moved,
+            "frac_moved": round(moved / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "traffic_source": src,
+            "frac_traffic": round(traffic / (t_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+            "avg_us": round(t_us, 3), "avg_us_rocprof": rp_us, "avg_us_rocprof_kernel": rp_name, "avg_us_rocprof_source": rp_file,
+            "note": "frac = SURVEY.md §8d's bytes for the steps this kernel replaces (FTRAN 8 m^2 + rank-1 update 16 m^2) / its "
+                    "duration; frac_moved = the bytes the fused pass has to move (one read and one write of B^-1, 16 m ld); "
+                    "tools/copy_floor.hip puts a copy of this shape at 11.4 us (config 3)."}
 
 
 def main():
@@ -432,7 +485,8 @@ def main():
                   "pricing_GBps_per_gpu": r5["achieved"] if r5 else None,
                   "pricing_frac_of_hbm_peak": r5["frac"] if r5 else None,
                   "pricing_GBps_all_gpus": round(r5["achieved"] * world, 1) if r5 else None,
-                  "roofline": r5, "kernels_us": {k: round(v["avg_us"], 3) for k, v in c5m["prof"].items()},
+                  "roofline": r5, "roofline_eta_pass": roofline_dominant(c5m, 4000, 40000, "primal", world),
+                  "kernels_us": {k: round(v["avg_us"], 3) for k, v in c5m["prof"].items()},
                   "achieved_GBps_algorithmic": round(c5_bytes * c5m["steps"] / c5m["dt"] / 1e9, 1),
                   "engine_GBps": round(c5m["engine_bytes_per_pivot"] * c5m["steps"] / c5m["dt"] / 1e9, 1),
                   "sharded_check": c5m.get("sharded_check")}
@@ -445,6 +499,7 @@ def main():
                           f"std-form 2000x{c4m['n_cols']} with |N|={c4m['nN']}",
               "value": round(c4m["steps"] / c4m["dt"], 2), "unit": "pivots/s", "steps": c4m["steps"],
               "ms_per_step": round(1e3 * c4m["dt"] / c4m["steps"], 6), "roofline": r4,
+              "roofline_dominant": roofline_dominant(c4m, 2000, 5000, "dual", 1),
               "kernels_us": {k: round(v["avg_us"], 3) for k, v in c4m["prof"].items()},
               "achieved_GBps_algorithmic": round(c4m["alg_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1),
               "engine_GBps": round(c4m["engine_bytes_per_pivot"] * c4m["steps"] / c4m["dt"] / 1e9, 1)}
@@ -542,6 +597,7 @@ def main():
     pivots_per_s = steps / dt
     flat = head["flat"]
     roofline = roofline_of(head, m, n, args.solver, world)
+    roof_dom = roofline_dominant(head, m, n, args.solver, world)
     cpu = None
     cpu_pivots = args.cpu_pivots
     if cpu_pivots < 0:
@@ -604,16 +660,19 @@ def main():
         "iteration_roofline": {"bytes_per_step_engine": head["engine_bytes_per_pivot"],
                                "achieved": round(head["engine_bytes_per_pivot"] * steps / dt / 1e9, 1), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(head["engine_bytes_per_pivot"] * steps / dt / 1e9 / HBM_PEAK_GBS, 4),
-                               "note": "THE quoted fraction: bytes the engine really moves per pivot (8 ld |N| for the pricing "
+                               "note": "bytes of the two passes as if every nonbasic column were streamed (8 ld |N| for the pricing "
                                        "pass + 16 m ld for the one pass that reads and rewrites B^-1; 24 m ld on the three-launch "
-                                       "form) / ms_per_step / 8 TB/s.  PMC traffic of every kernel equals these bytes within 2 % "
-                                       "(profiles/).",
+                                       "form) / ms_per_step / 8 TB/s.  The pricing pass streams fewer (unit columns, see "
+                                       "roofline.note): traffic_bytes_per_step / frac_traffic are the PMC bytes of the two kernels "
+                                       "(None without a counter file for the current engine sources).",
+                               "traffic_bytes_per_step": (roofline["traffic"] + roof_dom["traffic"]) if (roofline and roof_dom and roofline.get("traffic") and roof_dom.get("traffic")) else None,
+                               "frac_traffic": round((roofline["traffic"] + roof_dom["traffic"]) * steps / dt / 1e9 / HBM_PEAK_GBS, 4) if (roofline and roof_dom and roofline.get("traffic") and roof_dom.get("traffic")) else None,
                                "survey_bytes_per_step": alg_bytes_per_pivot,
                                "survey_frac": round(alg_gbps / HBM_PEAK_GBS, 4),
                                "survey_note": "SURVEY.md §8d's figure (8 m |N| + 32 m^2 primal, 24 m^2 dual: a B^-1 GEMV for BTRAN, "
                                               "one for FTRAN, a read + write for the update) counts bytes this engine no longer "
                                               "moves; kept for comparison with earlier rounds, not a claim"},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "roofline_dominant": roof_dom, "cpu_baseline": cpu,
         "kernels_us": {k: round(v["avg_us"], 3) for k, v in prof.items()}, "kernels_us_note": EVENT_NOTE,
     }
     if "long_window" in head:

@@ -23,6 +23,20 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-
             "-I" + os.path.join(HERE, "csrc", "engine")]
 
 
+def engine_source_hash():
+    """sha1 (12 hex digits) over the engine's sources and headers: profiles/ files carry it, so that bench.py can tell a
+    counter / kernel-time file measured on THESE kernels from one measured on an older build"""
+    import hashlib
+    h = hashlib.sha1()
+    edir = os.path.join(HERE, "csrc", "engine")
+    files = sorted(os.path.join(edir, f) for f in os.listdir(edir) if f.endswith((".hip", ".inc")))
+    files += sorted(os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _stale(target, sources):
     if not os.path.exists(target):
         return True

@@ -2665,6 +2665,83 @@ __global__ __launch_bounds__(256) void k_permute_cols(const double *src, double 
     double2 *d = reinterpret_cast<double2 *>(dst + (int64_t)blockIdx.x * ld);
     for (int64_t t = threadIdx.x; t < (ld >> 1); t += 256) d[t] = s[t];
 }
+// ---- certified hybrid, "certify or redo" (DESIGN.md §3.1c): the invariants the reference's loops maintain, measured on the
+// point a solve ended on.  out[0] = largest bound violation of x over all variables (primal…: every iterate is feasible);
+// out[1] = largest violation of the dual loop's entry assertion on d (dual_simplex_solver.rs:139-151, which holds at every
+// iteration of the reference's loop: Lower: d >= -EPS, Upper: d <= EPS, Free: |d| <= EPS); out[2] = the dual objective
+// recomputed from (y, d) (standard_form.rs:52-68), to be compared with the one the loop has carried (dual…:316).
+struct InvArgs {
+    const double *x, *lb, *ub, *b, *y, *dd;
+    const uint8_t *kind, *Nb;
+    const int64_t *N_index;
+    int64_t m, n_c, nN;
+    int dual;
+    double *out;
+};
+__global__ __launch_bounds__(1024) void k_invariants(InvArgs a) {
+    __shared__ double s_a[16], s_b[16], s_c[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double pv = 0.0, dv = 0.0, ob = 0.0;
+    for (int64_t i = tid; i < a.n_c; i += 1024) {
+        const int k = a.kind[i];
+        const double xi = a.x[i], l = a.lb[i], u = a.ub[i];
+        double v = 0.0;
+        if (k == ELLP_BOUND_LOWER) v = l - xi;
+        else if (k == ELLP_BOUND_UPPER) v = xi - u;
+        else if (k == ELLP_BOUND_TWOSIDED) v = fmax(l - xi, xi - u);
+        else if (k == ELLP_BOUND_FIXED) v = fabs(xi - l);
+        if (v != v) v = INFINITY;
+        pv = fmax(pv, v);
+        if (a.dual) {
+            const double di = a.dd[i];
+            if (k == ELLP_BOUND_LOWER) ob += l * di;
+            else if (k == ELLP_BOUND_UPPER) ob += u * di;
+            else if (k == ELLP_BOUND_TWOSIDED) ob += (di > 0.0) ? l * di : u * di;
+            else if (k == ELLP_BOUND_FIXED) ob += l * di;
+        }
+    }
+    if (a.dual) {
+        for (int64_t i = tid; i < a.m; i += 1024) ob += a.b[i] * a.y[i];
+        for (int64_t j = tid; j < a.nN; j += 1024) {
+            const double di = a.dd[a.N_index[j]];
+            const int nb = a.Nb[j];
+            double v = nb == ELLP_NB_LOWER ? -di : (nb == ELLP_NB_UPPER ? di : fabs(di));
+            if (v != v) v = INFINITY;
+            dv = fmax(dv, v);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        pv = fmax(pv, __shfl_xor(pv, o));
+        dv = fmax(dv, __shfl_xor(dv, o));
+        ob += __shfl_xor(ob, o);
+    }
+    if (lane == 0) {
+        s_a[wave] = pv;
+        s_b[wave] = dv;
+        s_c[wave] = ob;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) {
+            pv = fmax(pv, s_a[w]);
+            dv = fmax(dv, s_b[w]);
+            ob += s_c[w];
+        }
+        a.out[0] = pv;
+        a.out[1] = dv;
+        a.out[2] = ob;
+    }
+}
+// column j of the restored arrangement comes from A_B (src[j] >= 0: position) or A_N (src[j] < 0: position -1 - src[j])
+__global__ __launch_bounds__(256) void k_restore_cols(const double *A_B, const double *A_N, const int64_t *src, double *dst, int64_t ld) {
+    const int64_t j = blockIdx.x;
+    const int64_t sj = src[j];
+    const double2 *s = reinterpret_cast<const double2 *>(sj >= 0 ? A_B + sj * ld : A_N + (-1 - sj) * ld);
+    double2 *d = reinterpret_cast<double2 *>(dst + j * ld);
+    for (int64_t t = threadIdx.x; t < (ld >> 1); t += 256) d[t] = s[t];
+}
+
 struct DualRephaseArgs {
     const double *A_N, *A_B, *y, *c;
     const uint8_t *kind;
@@ -2888,7 +2965,17 @@ struct ellp_engine {
     bool hybrid = false;
     double guard_abs = 0.0;
     int exact_K = 8;
-    uint64_t hy_guards = 0, hy_certs = 0, hy_disagree = 0, hy_exact_iters = 0, hy_rebuilds = 0;
+    uint64_t hy_guards = 0, hy_certs = 0, hy_disagree = 0, hy_exact_iters = 0, hy_rebuilds = 0, hy_redos = 0;
+    // "certify or redo": the start of the phase (taken at the first run() after creation / a hand-off), so that a solve whose
+    // end point violates an invariant of the reference's loop can be repeated by the exact kernel from where it began
+    struct Snapshot {
+        bool valid = false;
+        std::vector<double> x, y, d, c_B, c_N;
+        std::vector<int64_t> B, N;
+        std::vector<uint8_t> Nb;
+        double obj = 0.0;
+    } snap;
+    double *inv_out = nullptr;
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
     int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
@@ -4559,6 +4646,125 @@ ellp_status ellp_engine_refactor(ellp_engine *e, char *errbuf, size_t errlen) {
 
 static ellp_status run_colsharded(ellp_engine *e, uint64_t max_iters, ellp_stats *stats, char *errbuf, size_t errlen);
 
+// ---- "certify or redo" (certified hybrid): the start of a phase is kept on the host; a solve that ends Optimal on a point
+// that violates an invariant of the reference's loop (see k_invariants) is repeated from that start by the exact kernel
+static hipError_t take_snapshot(ellp_engine *e) {
+    auto &sn = e->snap;
+    const size_t m = (size_t)e->m, nN = (size_t)e->nN, n_c = (size_t)e->n_c;
+    sn.x.resize(n_c); sn.B.resize(m); sn.N.resize(nN); sn.Nb.resize(nN); sn.c_B.resize(m); sn.c_N.resize(nN);
+    hipError_t rc;
+#define SNAP(dst, src, bytes) if ((rc = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return rc
+    SNAP(sn.x.data(), e->x, 8 * n_c);
+    SNAP(sn.B.data(), e->B_index, 8 * m);
+    SNAP(sn.N.data(), e->N_index, 8 * nN);
+    SNAP(sn.Nb.data(), e->Nb, nN);
+    SNAP(sn.c_B.data(), e->c_B, 8 * m);
+    SNAP(sn.c_N.data(), e->c_N, 8 * nN);
+    if (e->kind == ELLP_ENGINE_DUAL) {
+        sn.y.resize(m); sn.d.resize(n_c);
+        SNAP(sn.y.data(), e->y, 8 * m);
+        SNAP(sn.d.data(), e->dd, 8 * n_c);
+    }
+    SNAP(&sn.obj, &e->st->obj, sizeof(double));
+#undef SNAP
+    if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return rc;
+    sn.valid = true;
+    return hipSuccess;
+}
+
+// true if the end point keeps the invariants of the reference's loop to within EPS (or cannot be examined)
+static bool end_point_ok(ellp_engine *e, double *detail3) {
+    if (!e->inv_out && dmalloc(e, &e->inv_out, 4) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    InvArgs a{e->x, e->lb, e->ub, e->b_dev, e->y, e->dd, e->kindv, e->Nb, e->N_index, e->m, e->n_c, e->nN,
+              e->kind == ELLP_ENGINE_DUAL ? 1 : 0, e->inv_out};
+    hipLaunchKernelGGL(k_invariants, dim3(1), dim3(1024), 0, e->stream, a);
+    double out[3] = {0.0, 0.0, 0.0};
+    if (hipMemcpyAsync(out, e->inv_out, sizeof(out), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    if (detail3) { detail3[0] = out[0]; detail3[1] = out[1]; detail3[2] = out[2]; }
+    if (e->kind == ELLP_ENGINE_PRIMAL) return out[0] <= e->eps;
+    const double carried = e->h_st->obj;
+    return out[1] <= e->eps && std::fabs(out[2] - carried) <= e->eps * (1.0 + std::fabs(carried));
+}
+
+// back to the start of the phase, and from now on the LU-per-iteration kernel alone (ellp_mid.inc)
+static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errlen) {
+    const auto &sn = e->snap;
+    const int64_t m = e->m, nN = e->nN, ld = e->ld;
+    std::vector<int64_t> B((size_t)m), N((size_t)nN), where((size_t)e->n, INT64_MIN), src((size_t)(m + nN));
+    HIPCHK(hipMemcpy(B.data(), e->B_index, 8 * (size_t)m, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(N.data(), e->N_index, 8 * (size_t)nN, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < m; ++i) where[(size_t)B[(size_t)i]] = i;
+    for (int64_t j = 0; j < nN; ++j) where[(size_t)N[(size_t)j]] = -1 - j;
+    for (int64_t i = 0; i < m; ++i) src[(size_t)i] = where[(size_t)sn.B[(size_t)i]];
+    for (int64_t j = 0; j < nN; ++j) src[(size_t)(m + j)] = where[(size_t)sn.N[(size_t)j]];
+    for (int64_t k = 0; k < m + nN; ++k)
+        if (src[(size_t)k] == INT64_MIN) {
+            set_err(errbuf, errlen, "redo: the index sets of the snapshot and of the engine differ");
+            return ELLP_ERR_PANIC;
+        }
+    double *A2 = nullptr;
+    int64_t *src_dev = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&A2), sizeof(double) * (size_t)(ld * (m + nN))));
+    hipError_t rc = hipMalloc(reinterpret_cast<void **>(&src_dev), 8 * (size_t)(m + nN));
+    if (rc != hipSuccess) { (void)hipFree(A2); HIPCHK(rc); }
+    auto done = [&](hipError_t err) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipFree(A2);
+        (void)hipFree(src_dev);
+        return err;
+    };
+#define RCHK(expr) do { hipError_t _r = (expr); if (_r != hipSuccess) { HIPCHK(done(_r)); } } while (0)
+    RCHK(hipMemcpyAsync(src_dev, src.data(), 8 * (size_t)(m + nN), hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_restore_cols, dim3((unsigned)(m + nN)), dim3(256), 0, e->stream, e->A_B, e->A_N, src_dev, A2, ld);
+    RCHK(hipMemcpyAsync(e->A_B, A2, sizeof(double) * (size_t)(ld * m), hipMemcpyDeviceToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->A_N, A2 + ld * m, sizeof(double) * (size_t)(ld * nN), hipMemcpyDeviceToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->x, sn.x.data(), 8 * (size_t)e->n_c, hipMemcpyHostToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->B_index, sn.B.data(), 8 * (size_t)m, hipMemcpyHostToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->N_index, sn.N.data(), 8 * (size_t)nN, hipMemcpyHostToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->Nb, sn.Nb.data(), (size_t)nN, hipMemcpyHostToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->c_B, sn.c_B.data(), 8 * (size_t)m, hipMemcpyHostToDevice, e->stream));
+    RCHK(hipMemcpyAsync(e->c_N, sn.c_N.data(), 8 * (size_t)nN, hipMemcpyHostToDevice, e->stream));
+    if (e->kind == ELLP_ENGINE_DUAL) {
+        RCHK(hipMemcpyAsync(e->y, sn.y.data(), 8 * (size_t)m, hipMemcpyHostToDevice, e->stream));
+        RCHK(hipMemcpyAsync(e->dd, sn.d.data(), 8 * (size_t)e->n_c, hipMemcpyHostToDevice, e->stream));
+    }
+    DevState ns = *e->h_st;
+    ns.status = ST_RUNNING;
+    ns.nan_flag = 0; ns.tiny = 0; ns.tiny_p = 0; ns.fin = 0; ns.need_rebuild = 0; ns.panic_code = 0; ns.open = 0;
+    ns.pe_valid = 0; ns.mv_pending = 0; ns.se_valid = 0;
+    ns.iters = ns.pivots = ns.flips = 0;
+    ns.lambda = 0.0;
+    ns.obj = sn.obj;
+    ns.lr = -1;
+    *e->h_st = ns;
+    RCHK(hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream));
+    if (e->trace_len > 0) RCHK(hipMemsetAsync(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len, e->stream));
+    RCHK(done(hipSuccess));
+#undef RCHK
+    e->hybrid = false;
+    e->small = true;
+    e->mid = true;
+    e->w_valid = false;
+    e->lagged = false;
+    e->dual_fused = e->dual_fold = false;
+    e->lag_open = e->dual_open = false;
+    e->u_valid = false;
+    e->need_dleave = true;
+    e->maint_chain = 0;
+    e->enqueued = 0;
+    e->iters_seen = 0;
+    e->since_refactor = e->since_btran = e->since_drift = 0;
+    e->hy_redos += 1;
+    return ELLP_OPTIMAL;
+}
+
 // Certified hybrid (restated in oracle/ellp_oracle.c, hybrid_run): the explicit-inverse loop has stopped — on a guarded
 // pivot (ST_NEED_EXACT: nothing of that iteration is committed), on a terminal status, or on an error of its own arithmetic
 // (singular rebuild, NaN, an assertion of the reference).  h_st is the drained device state.  The LU-per-iteration kernel
@@ -4597,7 +4803,11 @@ static int exact_takeover(ellp_engine *e, uint64_t remaining, ellp_status *resul
     *e->h_st = ns;
     if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return fail(rc);
     const uint64_t K = budget < (uint64_t)e->exact_K ? budget : (uint64_t)e->exact_K;
-    if ((rc = launch_mid(e, K, e->kind == ELLP_ENGINE_DUAL ? 1 : 0)) != hipSuccess) return fail(rc);
+    static const int dual_resync = [] {  // diagnostics: ELLP_HYBRID_RESYNC = 1 (default) recomputes x_B only, 2 x_B, y and d
+        const char *v = getenv("ELLP_HYBRID_RESYNC");
+        return v && v[0] ? atoi(v) : 1;
+    }();
+    if ((rc = launch_mid(e, K, e->kind == ELLP_ENGINE_DUAL ? dual_resync : 0)) != hipSuccess) return fail(rc);
     if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
     if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
     const uint64_t did = e->h_st->iters - ns.iters;
@@ -4661,6 +4871,10 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     int64_t period = e->refactor_period;
     if (period <= 0) period = default_period(e);
     ellp_status result = ELLP_MAXITER;
+    if (e->hybrid && !e->snap.valid && e->world == 1 && !e->colshard && e->nN > 0 && getenv("ELLP_NO_REDO") == nullptr) {
+        launch_flush(e);
+        HIPCHK(take_snapshot(e));  // the start of the phase (certify or redo, see end_point_ok)
+    }
     if (e->nN == 0) {
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
     } else if (e->small && e->world == 1) {
@@ -4807,6 +5021,23 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             }
         }
     }
+    // Certify or redo: a hybrid solve that has ended Optimal (certified by the exact kernel) on a point that does not keep the
+    // invariants of the reference's loop — the explicit-inverse stretch has let x, or the dual's carried d, drift past EPS:
+    // the caller's next test on that point (the phase-1 objective against EPS, primal…:42-50 / dual…:45-50; the assertions of
+    // DualPhase2::from, dual_problem.rs:293-310) would fail where the reference's own arithmetic passes — is repeated from the
+    // start of the phase by the LU-per-iteration kernel alone: from there on the engine IS the reference's loop, bit for bit.
+    if (result == ELLP_OPTIMAL && e->hybrid && e->snap.valid && e->world == 1) {
+        double det[3] = {0.0, 0.0, 0.0};
+        if (!end_point_ok(e, det)) {
+            if (getenv("ELLP_HYBRID_DEBUG"))
+                fprintf(stderr, "ellp hybrid: end point violates an invariant (x %.3e, d %.3e, objective %.17g against the carried %.17g): redo\n",
+                        det[0], det[1], det[2], e->h_st->obj);
+            const ellp_status rs = redo_from_snapshot(e, errbuf, errlen);
+            if (rs != ELLP_OPTIMAL) return rs;
+            result = run_small(e, e->opts.max_iter, errbuf, errlen);
+            e->obj_fresh = false;
+        }
+    }
     // The caller's budget (ellp_opts.max_iter) is spent: the reference has run that many FULL loop bodies
     // (primal…:162-202), so an unbounded ray, a panic or a NaN found by the ratio test of the last one is its
     // result, not MaxIter.  On the two-launch pipeline that ratio test is still open (its fold belongs to the next
@@ -4925,6 +5156,10 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                         dst[25] = (double)e->hy_disagree;
                         dst[26] = (double)e->hy_exact_iters;
                         dst[27] = (double)e->hy_rebuilds;
+                        if (cap >= 29) {
+                            dst[28] = (double)e->hy_redos;  // solves repeated by the exact kernel from the start of the phase
+                            return 29;
+                        }
                         return 28;
                     }
                     return 22;
@@ -5237,6 +5472,7 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     e->maint_chain = 0;
     e->enqueued = 0;
     e->iters_seen = 0;
+    e->snap.valid = false;  // a new phase starts here
     return ELLP_OPTIMAL;
 }
 
@@ -5378,6 +5614,7 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
     e->maint_chain = 0;
     e->enqueued = 0;
     e->iters_seen = 0;
+    e->snap.valid = false;  // a new phase starts here
     if (e->trace_len > 0) HIPCHK(hipMemset(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len));
     return ELLP_OPTIMAL;
 }

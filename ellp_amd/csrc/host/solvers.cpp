@@ -8,6 +8,8 @@
 
 #include "ellp.h"
 
+#include <cstdlib>
+
 namespace ellp {
 
 namespace {
@@ -240,7 +242,9 @@ SolutionStatus run_resident_dual(ellp_engine *e, std::uint64_t max_iter, Flat &f
 SolverResult DualSimplexSolver::solve(Problem prob) const {
     SolverResult res;
     Problem orig_for_fallback = prob;  // phase_1.into_orig_prob()
-    auto p1 = DualPhase1::from_problem(std::move(prob), /*defer_point=*/true);
+    // ELLP_HOST_DUAL_POINT=1 (diagnostics): the starting point of phase 1 is made on the host, as the reference makes it
+    const char *hostpt = std::getenv("ELLP_HOST_DUAL_POINT");
+    auto p1 = DualPhase1::from_problem(std::move(prob), /*defer_point=*/!(hostpt && hostpt[0] == '1'));
     if (!p1) { res.kind = SolverResult::Infeasible; return res; }
     DualPhase1 phase_1 = std::move(*p1);
     const StandardForm &sf1 = phase_1.std_form;

@@ -2229,11 +2229,13 @@ done:
  *   4. terminal status S of fast (Optimal / Infeasible / Unbounded): run exact for up to K iterations.  If its FIRST
  *      iteration ends with S the status is certified and returned (the loop body that found it is counted once, as in the
  *      reference); if it ends otherwise, that is the result; if it pivots on, back to 1 with the counters advanced.
- *   Dual only: before every hand-over to the exact loop x_B, y and d are recomputed from a fresh LU of the basis,
- *   x_B = A_B^-1 (b - A_N x_N), y = A_B^-T c_B, d = c - A^T y — the leaving-row test (dual…:200-236) compares x_B with its
- *   bounds to within EPS = 1e-10, the caller tests the phase objective, a sum over d, against EPS (dual…:45-50), and what
- *   the inexact alpha of the fast loop has added to the carried vectors is far above that on ill-conditioned bases
- *   (ADLITTLE x 18, 1,008 rows: 8 of 30 dual phase 1 runs ended "dual infeasible" on the carried d).  The primal keeps
+ *   Dual only: before every hand-over to the exact loop x_B is recomputed from a fresh LU of the basis,
+ *   x_B = A_B^-1 (b - A_N x_N) — the leaving-row test (dual…:200-236) compares x_B with its bounds to within EPS = 1e-10,
+ *   and what the inexact alpha_q of the fast loop has added to the carried x_B is far above that on ill-conditioned
+ *   bases.  y and d stay the carried ones: recomputed from an LU of a basis of condition 1e7-1e9 they are themselves
+ *   only good to 1e-9..1e-8 (two LU codes differ by that much), and the caller tests sums over d against EPS = 1e-10
+ *   (dual…:45-50, dual_problem.rs:293-310) — measured both ways on ADLITTLE x 10 / x 18, the recomputed d fails those
+ *   tests more often than the carried one (EO_HYBRID_RESYNC_YD=1 keeps the other variant for the record).  The primal keeps
  *   the carried x: its exact zeros at degenerate vertices are worth more than a recomputation
  *   that returns -3e-9 for them (measured: tools/hybrid_cpu.py, phase-1 objectives of -1e-8 and the reference's
  *   assert!(obj > -EPS) after a resync; none without).
@@ -2256,7 +2258,7 @@ static void hybrid_resync(int64_t m, int64_t n, const double *A, const double *c
     if (lu_solve(&f, t)) { /* a singular basis keeps the carried vectors: the exact loop reports it */
         for (int64_t i = 0; i < m; ++i) x[B[i]] = t[i];
         for (int64_t i = 0; i < m; ++i) t[i] = c[B[i]];
-        if (getenv("EO_HYBRID_RESYNC_X_ONLY")) {
+        if (!getenv("EO_HYBRID_RESYNC_YD")) { /* default: x_B only — y and d are carried (see the header of this section) */
         } else if (lu_btran(&f, t)) { /* y = A_B^-T c_B, d = c - A^T y (dual_problem.rs:162-172 at this basis) */
             for (int64_t i = 0; i < m; ++i) y[i] = t[i];
             for (int64_t j = 0; j < nN; ++j) {
@@ -2275,7 +2277,7 @@ static void hybrid_resync(int64_t m, int64_t n, const double *A, const double *c
 }
 
 /* counters[0] hand-overs after a guard stop, [1] terminal statuses examined, [2] of those: not confirmed,
- * [3] iterations done by the exact loop */
+ * [3] iterations done by the exact loop, [4] solves repeated from their start by the exact loop (certify or redo) */
 static int hybrid_run(int dual, int64_t m, int64_t n, int64_t n_c, const double *A, const double *c, const double *b,
                       const uint8_t *kind, const double *lb, const double *ub, double *x, int64_t *B, int64_t nB,
                       int64_t *N, uint8_t *Nb, int64_t nN, double *y, double *d, uint64_t max_iter, uint64_t *iters_out,
@@ -2286,7 +2288,21 @@ static int hybrid_run(int dual, int64_t m, int64_t n, int64_t n_c, const double 
     const double save_rel = g_guard_rel, save_abs = g_guard_abs;
     const int save_cont = g_continuation;
     if (K < 1) K = 1;
-    if (counters) counters[0] = counters[1] = counters[2] = counters[3] = 0;
+    if (counters) counters[0] = counters[1] = counters[2] = counters[3] = counters[4] = 0;
+    /* the start of the solve, for "certify or redo" (below) */
+    double *x0 = NULL, *y0 = NULL, *d0 = NULL;
+    int64_t *B0 = NULL, *N0 = NULL;
+    uint8_t *Nb0 = NULL;
+    if (m > 0 && nB == m && nN == n - m && nN > 0) {
+        x0 = dcopy(x, n_c);
+        B0 = icopy(B, nB);
+        N0 = icopy(N, nN);
+        Nb0 = bcopy8(Nb, nN);
+        if (dual) {
+            y0 = dcopy(y, m);
+            d0 = dcopy(d, n_c);
+        }
+    }
     for (;;) {
         if (total >= max_iter) {
             status = EO_MAXITER;
@@ -2344,6 +2360,51 @@ static int hybrid_run(int dual, int64_t m, int64_t n, int64_t n_c, const double 
         }
     }
     g_continuation = save_cont;
+    /* certify or redo: the invariants the reference's loop maintains, measured on the end point to within EPS — primal: x
+     * within its bounds; dual: the loop's own entry assertion on d (dual…:139-151) and the dual objective recomputed from
+     * (y, d) (standard_form.rs:52-68) against the one the exact loop would carry (here: recomputed before and after is all
+     * the restatement has; the engine compares with the carried value).  Violated: the explicit-inverse stretch has let the
+     * point drift past EPS, and the solve is repeated from its start by the exact loop alone. */
+    if (status == EO_OPTIMAL && x0) {
+        int ok = 1;
+        if (!dual) {
+            for (int64_t i = 0; i < n_c && ok; ++i) {
+                double v = 0.0;
+                switch (kind[i]) {
+                case EO_LOWER: v = lb[i] - x[i]; break;
+                case EO_UPPER: v = x[i] - ub[i]; break;
+                case EO_TWOSIDED: v = fmax(lb[i] - x[i], x[i] - ub[i]); break;
+                case EO_FIXED: v = fabs(x[i] - lb[i]); break;
+                default: break;
+                }
+                if (!(v <= EPS)) ok = 0;
+            }
+        } else {
+            for (int64_t j = 0; j < nN && ok; ++j) {
+                const double di = d[N[j]];
+                const double v = Nb[j] == EO_NB_LOWER ? -di : (Nb[j] == EO_NB_UPPER ? di : fabs(di));
+                if (!(v <= EPS)) ok = 0;
+            }
+        }
+        if (!ok) {
+            memcpy(x, x0, sizeof(double) * (size_t)n_c);
+            memcpy(B, B0, sizeof(int64_t) * (size_t)nB);
+            memcpy(N, N0, sizeof(int64_t) * (size_t)nN);
+            memcpy(Nb, Nb0, (size_t)nN);
+            if (dual) {
+                memcpy(y, y0, sizeof(double) * (size_t)m);
+                memcpy(d, d0, sizeof(double) * (size_t)n_c);
+            }
+            uint64_t it3 = 0;
+            if (dual)
+                status = eo_dual_solve_with_initial(m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, y, d, max_iter, &it3, err, errlen);
+            else
+                status = eo_primal_solve_with_initial(m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, max_iter, &it3, err, errlen);
+            total = it3;
+            if (counters) counters[4] += 1;
+        }
+    }
+    free(x0); free(B0); free(N0); free(Nb0); free(y0); free(d0);
     if (iters_out) *iters_out = total;
     return status;
 }
@@ -2352,18 +2413,18 @@ int eo_primal_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const
                                         const double *b, const uint8_t *kind, const double *lb, const double *ub,
                                         double *x, int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
                                         uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
-                                        int threads, uint64_t *counters4, char *err, size_t errlen) {
+                                        int threads, uint64_t *counters5, char *err, size_t errlen) {
     return hybrid_run(0, m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, NULL, NULL, max_iter, iters, K, guard_abs,
-                      refresh, threads, counters4, err, errlen);
+                      refresh, threads, counters5, err, errlen);
 }
 
 int eo_dual_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
                                       const double *b, const uint8_t *kind, const double *lb, const double *ub, double *x,
                                       int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y, double *d,
                                       uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
-                                      int threads, uint64_t *counters4, char *err, size_t errlen) {
+                                      int threads, uint64_t *counters5, char *err, size_t errlen) {
     return hybrid_run(1, m, n, n_c, A, c, b, kind, lb, ub, x, B, nB, N, Nb, nN, y, d, max_iter, iters, K, guard_abs, refresh,
-                      threads, counters4, err, errlen);
+                      threads, counters5, err, errlen);
 }
 
 /* ------------------------------------------------------------------ DualPhase1 / DualPhase2 */

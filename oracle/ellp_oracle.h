@@ -150,18 +150,19 @@ int eo_dual_binv_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const dou
 /* The CERTIFIED HYBRID (round 4; not the reference's loop — the engine's default policy above 128 rows, restated; see
  * ellp_oracle.c): the explicit-inverse loop with a pivot guard (|pivot| < guard_abs stops it before the iteration is
  * committed), every terminal status and every guarded iteration handed to the LU-per-iteration loop for up to K iterations.
- * counters4: [0] hand-overs after a guard stop, [1] terminal statuses examined, [2] of those not confirmed, [3] iterations
- * of the exact loop. */
+ * counters5: [0] hand-overs after a guard stop, [1] terminal statuses examined, [2] of those not confirmed, [3] iterations
+ * of the exact loop, [4] solves repeated from their start by the exact loop because the end point violated an invariant of
+ * the reference's loop ("certify or redo"). */
 int eo_primal_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
                                         const double *b, const uint8_t *kind, const double *lb, const double *ub,
                                         double *x, int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN,
                                         uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
-                                        int threads, uint64_t *counters4, char *err, size_t errlen);
+                                        int threads, uint64_t *counters5, char *err, size_t errlen);
 int eo_dual_hybrid_solve_with_initial(int64_t m, int64_t n, int64_t n_c, const double *A, const double *c,
                                       const double *b, const uint8_t *kind, const double *lb, const double *ub, double *x,
                                       int64_t *B, int64_t nB, int64_t *N, uint8_t *Nb, int64_t nN, double *y, double *d,
                                       uint64_t max_iter, uint64_t *iters, int K, double guard_abs, int refresh,
-                                      int threads, uint64_t *counters4, char *err, size_t errlen);
+                                      int threads, uint64_t *counters5, char *err, size_t errlen);
 
 /* Optional per-iteration trace for pivot-sequence parity (entering position, leaving
  * position or -1, objective). Set to NULL to disable.  Not thread-safe (test use only). */

@@ -362,10 +362,10 @@ HYBRID_GUARD_ABS = 1e-7  # a pivot below this is not taken by the explicit-inver
 def primal_hybrid_solve_with_initial(ph, max_iter=MAX_ITER_NONE, K=HYBRID_K, guard_abs=HYBRID_GUARD_ABS, refresh=64, threads=1):
     """The certified hybrid (the engine's default policy above 128 rows, restated in ellp_oracle.c), primal, in place on a
     Phase view.  Returns (status, iters, err, counters) with counters = [guard hand-overs, terminal statuses examined,
-    not confirmed, exact iterations]."""
+    not confirmed, exact iterations, solves repeated by the exact loop]."""
     it = C.c_uint64(0)
     err = C.create_string_buffer(256)
-    cnt = np.zeros(4, dtype=np.uint64)
+    cnt = np.zeros(5, dtype=np.uint64)
     st = lib().eo_primal_hybrid_solve_with_initial(
         ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
         _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,
@@ -377,7 +377,7 @@ def dual_hybrid_solve_with_initial(ph, max_iter=MAX_ITER_NONE, K=HYBRID_K, guard
     """The certified hybrid, dual.  Returns (status, iters, err, counters)."""
     it = C.c_uint64(0)
     err = C.create_string_buffer(256)
-    cnt = np.zeros(4, dtype=np.uint64)
+    cnt = np.zeros(5, dtype=np.uint64)
     st = lib().eo_dual_hybrid_solve_with_initial(
         ph.m, ph.n, ph.n_c, _ptr(ph.A), _ptr(ph.c), _ptr(ph.b), _ptr(ph.kind), _ptr(ph.lb),
         _ptr(ph.ub), _ptr(ph.x), _ptr(ph.B), ph.nB, _ptr(ph.N), _ptr(ph.Nb), ph.nN,

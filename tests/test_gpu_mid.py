@@ -106,16 +106,25 @@ def test_random_bound_kinds_bit_for_bit():
     assert ran >= 8
 
 
-def test_default_is_the_exact_kernel_up_to_512_rows():
+def test_defaults_by_size():
+    """pipeline = 0: up to 128 rows the exact kernel with its factors in LDS (0 launches per iteration: whole iterations
+    inside one persistent launch); 129-1024 rows the CERTIFIED HYBRID on the three-launch pipeline (round 3: this
+    kernel alone up to 512 rows); above, two launches per iteration; pipeline = 3 still selects this kernel up to 1024"""
     E = _E()
     from ellp_amd import synth
-    for m, n, want in ((200, 400, 0), (512, 900, 0), (513, 900, 2)):
+    for m, n, want, hybrid in ((100, 260, 0, False), (200, 400, 3, True), (512, 900, 3, True), (1024, 1500, 3, True), (1025, 1500, 2, False)):
         f = synth.primal_phase1_flat(5, m, n)
         fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
                            f["B"], f["N"], f["Nb"])
         eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
-        assert eng.counters()["launches_per_iteration"] == want, m
+        c = eng.counters()
+        assert c["launches_per_iteration"] == want and c["hybrid"] == hybrid, (m, c)
         eng.close()
+        if 128 < m <= 1024:
+            eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, pipeline=3))
+            c = eng.counters()
+            assert c["launches_per_iteration"] == 0 and not c["hybrid"], (m, c)
+            eng.close()
 
 
 def test_slices_and_hand_over_to_the_explicit_inverse():
@@ -134,7 +143,7 @@ def test_slices_and_hand_over_to_the_explicit_inverse():
     st_o, it_o, _ = eo.primal_solve_with_initial(ov, 150)
     fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"],
                        f["B"], f["N"], f["Nb"])
-    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None, pipeline=3))
     total = 0
     for k in (1, 2, 47, 100):
         st, stats, msg = eng.run(k)
