@@ -2666,10 +2666,11 @@ __global__ __launch_bounds__(256) void k_permute_cols(const double *src, double 
     for (int64_t t = threadIdx.x; t < (ld >> 1); t += 256) d[t] = s[t];
 }
 // ---- certified hybrid, "certify or redo" (DESIGN.md §3.1c): the invariants the reference's loops maintain, measured on the
-// point a solve ended on.  out[0] = largest bound violation of x over all variables (primal…: every iterate is feasible);
-// out[1] = largest violation of the dual loop's entry assertion on d (dual_simplex_solver.rs:139-151, which holds at every
-// iteration of the reference's loop: Lower: d >= -EPS, Upper: d <= EPS, Free: |d| <= EPS); out[2] = the dual objective
-// recomputed from (y, d) (standard_form.rs:52-68), to be compared with the one the loop has carried (dual…:316).
+// point a solve ended on.  out[0] = SUM of the bound violations of x over all variables (every iterate of the primal loop is
+// feasible; the caller's phase-1 test, primal…:42-50, is on a sum: the objective over the artificials); out[1] = SUM of the
+// violations of the dual loop's entry assertion on d (dual_simplex_solver.rs:139-151, which holds at every iteration of the
+// reference's loop: Lower: d >= 0, Upper: d <= 0, Free: d = 0; the caller's phase-1 test, dual…:45-50, is again a sum);
+// out[2] = the dual objective recomputed from (y, d) (standard_form.rs:52-68), for diagnostics.
 struct InvArgs {
     const double *x, *lb, *ub, *b, *y, *dd;
     const uint8_t *kind, *Nb;
@@ -2691,7 +2692,7 @@ __global__ __launch_bounds__(1024) void k_invariants(InvArgs a) {
         else if (k == ELLP_BOUND_TWOSIDED) v = fmax(l - xi, xi - u);
         else if (k == ELLP_BOUND_FIXED) v = fabs(xi - l);
         if (v != v) v = INFINITY;
-        pv = fmax(pv, v);
+        if (v > 0.0) pv += v;
         if (a.dual) {
             const double di = a.dd[i];
             if (k == ELLP_BOUND_LOWER) ob += l * di;
@@ -2707,13 +2708,13 @@ __global__ __launch_bounds__(1024) void k_invariants(InvArgs a) {
             const int nb = a.Nb[j];
             double v = nb == ELLP_NB_LOWER ? -di : (nb == ELLP_NB_UPPER ? di : fabs(di));
             if (v != v) v = INFINITY;
-            dv = fmax(dv, v);
+            if (v > 0.0) dv += v;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        pv = fmax(pv, __shfl_xor(pv, o));
-        dv = fmax(dv, __shfl_xor(dv, o));
+        pv += __shfl_xor(pv, o);
+        dv += __shfl_xor(dv, o);
         ob += __shfl_xor(ob, o);
     }
     if (lane == 0) {
@@ -2724,8 +2725,8 @@ __global__ __launch_bounds__(1024) void k_invariants(InvArgs a) {
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < 16; ++w) {
-            pv = fmax(pv, s_a[w]);
-            dv = fmax(dv, s_b[w]);
+            pv += s_a[w];
+            dv += s_b[w];
             ob += s_c[w];
         }
         a.out[0] = pv;
@@ -2976,6 +2977,9 @@ struct ellp_engine {
         double obj = 0.0;
     } snap;
     double *inv_out = nullptr;
+    // the LP is a "box problem" — every bound TwoSided or Fixed and b = 0: the shape of DualPhase1's LP (dual_problem.rs:89-131),
+    // whose dual objective is minus the dual infeasibility of the original problem, i.e. <= 0 and = 0 at a feasible end
+    bool box_problem = false;
     double ill_tol = 0.0;  // reactive maintenance threshold (small LPs only, see ellp_engine_create)
     int maint_chain = 0;   // > 0: refresh again after the next single iteration
     int drift_every = 0;   // iterations between two drift checks of B^-1 (0: off)
@@ -4319,6 +4323,12 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         }
     }
     e->dual_maxviol = (kind == ELLP_ENGINE_DUAL && (e->opts.flags & ELLP_FLAG_DUAL_MAX_VIOLATION)) ? 1 : 0;
+    if (kind == ELLP_ENGINE_DUAL) {
+        bool box = true;
+        for (int64_t i = 0; i < n_c && box; ++i) box = bound_kind[i] == ELLP_BOUND_TWOSIDED || bound_kind[i] == ELLP_BOUND_FIXED;
+        for (int64_t i = 0; i < m && box; ++i) box = b[i] == 0.0;
+        e->box_problem = box;
+    }
     e->se = kind == ELLP_ENGINE_PRIMAL && (e->opts.flags & ELLP_FLAG_PRIMAL_STEEPEST_EDGE) && n_N > 0 && e->pp_P <= 1;
     // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the pricing
     // kernels of both loops consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.
@@ -4689,8 +4699,11 @@ static bool end_point_ok(ellp_engine *e, double *detail3) {
     }
     if (detail3) { detail3[0] = out[0]; detail3[1] = out[1]; detail3[2] = out[2]; }
     if (e->kind == ELLP_ENGINE_PRIMAL) return out[0] <= e->eps;
-    const double carried = e->h_st->obj;
-    return out[1] <= e->eps && std::fabs(out[2] - carried) <= e->eps * (1.0 + std::fabs(carried));
+    if (!(out[1] <= e->eps)) return false;
+    // a box problem's dual objective (= minus the original problem's dual infeasibility, the number the caller tests against
+    // EPS, dual…:45-50) that lies BELOW -EPS but within what the drift of the carried d can produce: the exact loop decides
+    if (e->box_problem && out[2] <= -e->eps && out[2] > -1e-6) return false;
+    return true;
 }
 
 // back to the start of the phase, and from now on the LU-per-iteration kernel alone (ellp_mid.inc)
@@ -5483,13 +5496,23 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
 static ellp_status dual_point_from_inverse(ellp_engine *e, const double *c_dev, int phase1, const int64_t *N_host,
                                            char *errbuf, size_t errlen) {
     const int64_t m = e->m, nN = e->nN, ld = e->ld, n_c = e->n_c;
-    launch_btran(e);  // into e->u (a dual engine has no other use for it)
-    HIPCHK(hipMemcpyAsync(e->y, e->u, sizeof(double) * (size_t)ld, hipMemcpyDeviceToDevice, e->stream));
+    // Certified-hybrid engines take y (and, below, x_B) from a fresh LU of the basis — the LU-per-iteration kernel with zero
+    // iterations — as the reference does (dual_problem.rs:162-172, :275-284), not from the explicit inverse: the point is the
+    // START of a phase whose carried d the caller will test against EPS at its end, and a d that starts 1e-9 off stays 1e-9 off
+    // even when the exact kernel repeats the phase.
+    const bool from_lu = e->hybrid && e->LUa != nullptr && e->world == 1;
+    if (from_lu) {
+        HIPCHK(launch_mid(e, 0, 2));
+    } else {
+        launch_btran(e);  // into e->u (a dual engine has no other use for it)
+        HIPCHK(hipMemcpyAsync(e->y, e->u, sizeof(double) * (size_t)ld, hipMemcpyDeviceToDevice, e->stream));
+    }
     HIPCHK(hipMemsetAsync(e->x, 0, sizeof(double) * (size_t)n_c, e->stream));
     DualRephaseArgs da{e->A_N, e->A_B, e->y, c_dev, e->kindv, e->lb, e->ub, e->N_index, e->B_index, e->dd, e->x, e->Nb,
                        e->st, m, ld, nN, e->eps, phase1};
     hipLaunchKernelGGL(k_dual_rephase, dim3((unsigned)((nN + m + 3) / 4)), dim3(256), 0, e->stream, da);
     launch_resync(e, 1);
+    if (from_lu) HIPCHK(launch_mid(e, 0, 1));  // x_B = A_B^-1 (b - A_N x_N) from the LU
     std::vector<double> d((size_t)n_c);
     std::vector<uint8_t> Nb((size_t)(nN > 0 ? nN : 1));
     HIPCHK(hipMemcpyAsync(d.data(), e->dd, sizeof(double) * (size_t)n_c, hipMemcpyDeviceToHost, e->stream));
@@ -5615,6 +5638,12 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
     e->enqueued = 0;
     e->iters_seen = 0;
     e->snap.valid = false;  // a new phase starts here
+    {
+        bool box = true;
+        for (int64_t i = 0; i < n_c && box; ++i) box = bound_kind[i] == ELLP_BOUND_TWOSIDED || bound_kind[i] == ELLP_BOUND_FIXED;
+        for (int64_t i = 0; i < m && box; ++i) box = b[i] == 0.0;
+        e->box_problem = box;
+    }
     if (e->trace_len > 0) HIPCHK(hipMemset(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len));
     return ELLP_OPTIMAL;
 }

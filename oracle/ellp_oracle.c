@@ -2361,14 +2361,12 @@ static int hybrid_run(int dual, int64_t m, int64_t n, int64_t n_c, const double 
     }
     g_continuation = save_cont;
     /* certify or redo: the invariants the reference's loop maintains, measured on the end point to within EPS — primal: x
-     * within its bounds; dual: the loop's own entry assertion on d (dual…:139-151) and the dual objective recomputed from
-     * (y, d) (standard_form.rs:52-68) against the one the exact loop would carry (here: recomputed before and after is all
-     * the restatement has; the engine compares with the carried value).  Violated: the explicit-inverse stretch has let the
-     * point drift past EPS, and the solve is repeated from its start by the exact loop alone. */
+     * within its bounds; dual: the loop's own entry assertion on d (dual…:139-151).  Violated: the explicit-inverse
+     * stretch has let the point drift past EPS, and the solve is repeated from its start by the exact loop alone. */
     if (status == EO_OPTIMAL && x0) {
-        int ok = 1;
+        double viol = 0.0; /* the SUM of the violations: the caller's phase-1 tests (primal…:42-50, dual…:45-50) are on sums */
         if (!dual) {
-            for (int64_t i = 0; i < n_c && ok; ++i) {
+            for (int64_t i = 0; i < n_c; ++i) {
                 double v = 0.0;
                 switch (kind[i]) {
                 case EO_LOWER: v = lb[i] - x[i]; break;
@@ -2377,16 +2375,28 @@ static int hybrid_run(int dual, int64_t m, int64_t n, int64_t n_c, const double 
                 case EO_FIXED: v = fabs(x[i] - lb[i]); break;
                 default: break;
                 }
-                if (!(v <= EPS)) ok = 0;
+                if (v != v) v = INFINITY;
+                if (v > 0.0) viol += v;
             }
         } else {
-            for (int64_t j = 0; j < nN && ok; ++j) {
+            for (int64_t j = 0; j < nN; ++j) {
                 const double di = d[N[j]];
-                const double v = Nb[j] == EO_NB_LOWER ? -di : (Nb[j] == EO_NB_UPPER ? di : fabs(di));
-                if (!(v <= EPS)) ok = 0;
+                double v = Nb[j] == EO_NB_LOWER ? -di : (Nb[j] == EO_NB_UPPER ? di : fabs(di));
+                if (v != v) v = INFINITY;
+                if (v > 0.0) viol += v;
+            }
+            /* a "box problem" (every bound TwoSided or Fixed, b = 0: DualPhase1's LP, dual_problem.rs:89-131): its dual
+             * objective is minus the original problem's dual infeasibility, the number the caller tests against EPS
+             * (dual…:45-50); below -EPS but within what the drift of the carried d can produce, the exact loop decides */
+            int box = 1;
+            for (int64_t i = 0; i < n_c && box; ++i) box = kind[i] == EO_TWOSIDED || kind[i] == EO_FIXED;
+            for (int64_t i = 0; i < m && box; ++i) box = b[i] == 0.0;
+            if (box) {
+                const double o = dual_obj(m, n_c, b, kind, lb, ub, y, d);
+                if (o <= -EPS && o > -1e-6) viol = INFINITY;
             }
         }
-        if (!ok) {
+        if (!(viol <= EPS)) {
             memcpy(x, x0, sizeof(double) * (size_t)n_c);
             memcpy(B, B0, sizeof(int64_t) * (size_t)nB);
             memcpy(N, N0, sizeof(int64_t) * (size_t)nN);
