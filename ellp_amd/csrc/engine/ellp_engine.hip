@@ -4329,6 +4329,14 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         for (int64_t i = 0; i < m && box; ++i) box = b[i] == 0.0;
         e->box_problem = box;
     }
+    if (kind == ELLP_ENGINE_PRIMAL && (e->opts.flags & ELLP_FLAG_PRIMAL_STEEPEST_EDGE) &&
+        (e->pp_P > 1 || e->opts.pipeline == 2 || e->opts.pipeline == 3 || e->opts.btran_mode == 1)) {
+        // the caller must be able to tell which rule ran: steepest edge exists on the three-launch explicit-inverse engine only
+        set_err(errbuf, errlen, "ELLP_FLAG_PRIMAL_STEEPEST_EDGE runs on the three-launch pipeline (pipeline 0 or 1) with full "
+                                "pricing and the incremental BTRAN: not with partial_segments > 1, pipeline 2 / 3 or btran_mode 1");
+        ellp_engine_destroy(e);
+        return ELLP_ERR_ARG;
+    }
     e->se = kind == ELLP_ENGINE_PRIMAL && (e->opts.flags & ELLP_FLAG_PRIMAL_STEEPEST_EDGE) && n_N > 0 && e->pp_P <= 1;
     // unit columns of the matrix (slacks, artificials, any other column with a single nonzero): the table the pricing
     // kernels of both loops consult (PriceArgs::vs_row).  ellp_opts.flags bit 0 or ELLP_NO_UNIT_COLUMNS=1: off.

@@ -38,7 +38,7 @@ namespace {
 struct QrState {
     int64_t pj;       // pivot column of the current step
     int32_t skip;     // factor == 0: no reflector to apply (dense.h: `continue`)
-    int32_t pad;
+    int32_t near_tie; // fast mode: some step's two best pivot candidates were within 1e-12 (relative) of each other
 };
 
 // per-column candidate for the next pivot search: cand[j] = max_r |M[r, j]| over the trailing rows
@@ -60,39 +60,54 @@ __global__ __launch_bounds__(256) void k_qr_scan(const double *A, int64_t m, int
 // i and pj of M (rows i, pj of A) and copies the pivot column's trailing part to xbuf.
 __global__ __launch_bounds__(256) void k_qr_swap(double *A, int64_t m, int64_t nv, int64_t i, const double *cand,
                                                  double *xbuf, QrState *st, int64_t *pivot_out) {
-    __shared__ double s_v[4];
+    __shared__ double s_v[4], s_2[4];
     __shared__ long long s_j[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double bv = -1.0;
+    double bv = -1.0, sv = -1.0;  // the best candidate and the value of the second best (for the near-tie test of the fast mode)
     long long bj = -1;
     for (int64_t j = i + tid; j < m; j += 256) {
         const double v = cand[j];
         if (bj < 0 || v > bv) {  // this thread's j ascend: strict '>' keeps its lowest j
+            sv = bv;
             bv = v;
             bj = j;
+        } else if (v > sv) {
+            sv = v;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(bv, o);
+        const double ov = __shfl_xor(bv, o), os = __shfl_xor(sv, o);
         const long long oj = __shfl_xor(bj, o);
         if (oj >= 0 && (bj < 0 || ov > bv || (ov == bv && oj < bj))) {
+            sv = fmax(fmax(sv, os), bj >= 0 ? bv : -1.0);
             bv = ov;
             bj = oj;
+        } else {
+            sv = fmax(fmax(sv, os), oj >= 0 ? ov : -1.0);
         }
     }
     if (lane == 0) {
         s_v[wave] = bv;
+        s_2[wave] = sv;
         s_j[wave] = bj;
     }
     __syncthreads();
     bv = s_v[0];
+    sv = s_2[0];
     bj = s_j[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 4; ++w) {
         if (s_j[w] >= 0 && (bj < 0 || s_v[w] > bv || (s_v[w] == bv && s_j[w] < bj))) {
+            sv = fmax(fmax(sv, s_2[w]), bj >= 0 ? bv : -1.0);
             bv = s_v[w];
             bj = s_j[w];
+        } else {
+            sv = fmax(fmax(sv, s_2[w]), s_j[w] >= 0 ? s_v[w] : -1.0);
         }
+    }
+    // two candidates closer than the parallel reductions of the fast mode can tell apart (they agree with the host loop's
+    // sums to ~1e-14 relative): the host re-runs the factorisation in the exact mode (ellp_hip_qr_transposed)
+    if (blockIdx.x == 0 && tid == 0 && sv >= 0.0 && bv > 0.0 && bv - sv <= 1e-12 * bv) st->near_tie = 1;
     const int64_t pj = bj;
     if (blockIdx.x == 0 && tid == 0) {
         st->pj = pj;
@@ -400,8 +415,8 @@ void set_err(char *errbuf, size_t len, const char *msg, hipError_t e) {
 
 }  // namespace
 
-extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out,
-                                              double *rdiag_out, int device, char *errbuf, size_t errlen) {
+static ellp_status qr_transposed_impl(int64_t m, int64_t nv, const double *A, int64_t *pivot_out, double *rdiag_out, int device,
+                                      char *errbuf, size_t errlen, bool exact, int *near_tie) {
     if (errbuf && errlen) errbuf[0] = 0;
     if (m < 0 || nv < 0 || (m > 0 && nv > 0 && (!A || !pivot_out || !rdiag_out))) return ELLP_ERR_ARG;
     const int64_t mn = m < nv ? m : nv;
@@ -412,8 +427,6 @@ extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const doubl
         return ELLP_ERR_DEVICE;
     }
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return ELLP_ERR_DEVICE;
-    const char *exact_env = getenv("ELLP_QR_EXACT");
-    const bool exact = exact_env && exact_env[0] == '1';
     constexpr int MAXCHUNK = 64;
     double *dA = nullptr, *xbuf = nullptr, *cand = nullptr, *rdiag = nullptr, *f2 = nullptr, *part = nullptr;
     int64_t *piv = nullptr;
@@ -486,8 +499,28 @@ extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const doubl
     QCHK(hipGetLastError());
     QCHK(hipMemcpyAsync(pivot_out, piv, sizeof(int64_t) * (size_t)mn, hipMemcpyDeviceToHost, stream));
     QCHK(hipMemcpyAsync(rdiag_out, rdiag, sizeof(double) * (size_t)mn, hipMemcpyDeviceToHost, stream));
+    QrState hs{};
+    QCHK(hipMemcpyAsync(&hs, st, sizeof(QrState), hipMemcpyDeviceToHost, stream));
     QCHK(hipStreamSynchronize(stream));
 #undef QCHK
     cleanup();
+    if (near_tie) *near_tie = hs.near_tie;
     return ELLP_OPTIMAL;
+}
+
+// Fast mode by default; a factorisation in which two pivot candidates came closer than the fast mode's parallel reductions
+// can tell apart (1e-12 relative: exact ties included — the many equal entries of real LPs) is done again in the exact mode,
+// whose every number is the host loop's: the pivot order — which standard_form.rs:142-181 turns into the ROW ORDER of the
+// standard form, hence into the basis order and every tie-break downstream — is then the host's and the reference's in
+// every case.  ELLP_QR_EXACT=1: exact from the start; ELLP_QR_EXACT=0: fast without the fall-back (measurements).
+extern "C" ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out,
+                                              double *rdiag_out, int device, char *errbuf, size_t errlen) {
+    const char *exact_env = getenv("ELLP_QR_EXACT");
+    const bool exact = exact_env && exact_env[0] == '1';
+    const bool no_fallback = exact_env && exact_env[0] == '0';
+    int near_tie = 0;
+    ellp_status s = qr_transposed_impl(m, nv, A, pivot_out, rdiag_out, device, errbuf, errlen, exact, &near_tie);
+    if (s == ELLP_OPTIMAL && !exact && !no_fallback && near_tie)
+        s = qr_transposed_impl(m, nv, A, pivot_out, rdiag_out, device, errbuf, errlen, true, nullptr);
+    return s;
 }

@@ -391,10 +391,12 @@ void ellp_engine_destroy(ellp_engine *e);
  * QR of A^T (src/standard_form.rs:142 `A.transpose().col_piv_qr()`), reduced to what :143-181
  * consume.  A: m x nv column-major (ld = m) in HOST memory, not modified.  pivot_out[i] = the
  * column of A^T (row of A) swapped into position i at step i (the transposition list),
- * rdiag_out[i] = |R_ii|, both of length min(m, nv).  Default (fast mode): the host loop's steps with norms and dot
- * products reduced in parallel — the same pivots up to the rank, |R_ii| to rounding, reproducible from run to run.
- * With ELLP_QR_EXACT=1 in the environment every floating-point result is bitwise what the host loop of
- * ellp_amd/csrc/host/dense.h (ColPivQR) produces (4x slower).  device < 0: current device.
+ * rdiag_out[i] = |R_ii|, both of length min(m, nv).  Default: the host loop's steps with norms and dot products reduced in
+ * parallel (fast mode; |R_ii| to rounding, reproducible from run to run) — and, if at any step the two best pivot candidates
+ * were closer than those reductions can tell apart (1e-12 relative, exact ties included), the factorisation is done again in
+ * the exact mode, in which every floating-point result is bitwise what the host loop of ellp_amd/csrc/host/dense.h
+ * (ColPivQR) produces (4x slower): the pivot order is the host loop's in every case.  ELLP_QR_EXACT=1 in the environment:
+ * exact from the start; ELLP_QR_EXACT=0: fast without the fall-back (measurements).  device < 0: current device.
  */
 ellp_status ellp_hip_qr_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out, double *rdiag_out,
                                    int device, char *errbuf, size_t errbuf_len);

@@ -94,8 +94,8 @@ void eo_set_dual_rule(int bits) { g_dual_rule = bits; }
 /* Primal extension (NOT the reference's rule, off by default; eo_set_primal_rule(1)): steepest-edge
  * pricing.  Every nonbasic position carries gamma_j = 1 + |B^-1 a_j|^2 (exact at the start, whatever the basis); the entering candidates are the reference's
  * (primal…:253-270) but the key that goes through the reference's fold (:271-287) is |r_j| / sqrt(gamma_j) instead of |r_j|.
- * gamma is exact at a basis that is a signed permutation (every phase-1 start: 1 + |a_j|^2) and starts at 1 otherwise
- * (a reference-framework reset); after a pivot (entering position q, leaving row r, alpha_q = B^-1 a_q, rho = row r of
+ * gamma is exact at the start at EVERY basis: 1 + |a_j|^2 read off the columns at a signed permutation (every phase-1 start),
+ * 1 + |B^-1 a_j|^2 from one LU of the basis otherwise (the engine: from the inverse it has just built); after a pivot (entering position q, leaving row r, alpha_q = B^-1 a_q, rho = row r of
  * B^-1, v = B^-T alpha_q) it is updated exactly (Goldfarb & Reid): with abar_j = (rho . a_j) / alpha_q[r],
  *   gamma_j <- max(gamma_j - 2 abar_j (a_j . v) + abar_j^2 gamma_q, 1 + abar_j^2),   gamma_leaving <- max(gamma_q / alpha_q[r]^2, 1)
  * with gamma_q = 1 + |alpha_q|^2 taken exactly; a bound flip leaves the weights alone.

@@ -26,8 +26,9 @@ def _rule():
 
 @pytest.mark.parametrize("m,n,flags", [(100, 250, SE), (200, 500, SE), (200, 500, SE | 1), (150, 2000, SE)])
 def test_pivots_of_the_restated_rule_and_the_known_optimum(m, n, flags):
-    """Both phases at the seam (phase 1 starts from a signed permutation: exact weights; phase 2 from a general basis:
-    weights reset to 1 — on both sides); flags | 1: every column streamed (no unit-column shortcut in the SE kernel).
+    """Both phases at the seam (phase 1 starts from a signed permutation: exact weights from the columns; phase 2 from a
+    general basis: exact weights 1 + |B^-1 a_j|^2, the oracle from one LU, the engine from the inverse it has just built);
+    flags | 1: every column streamed (no unit-column shortcut in the SE kernel).
     The weights are sums with cancellation: oracle (fresh LU) and engine (explicit inverse) hold them to 1e-12, not to the
     bit, so after some hundreds of pivots a near-tie of two keys r_j^2 / gamma_j can fall the other way and the paths part
     (both are the rule's paths).  Pinned: the same pivots over phase 1 and over the first 150 iterations of phase 2; from
