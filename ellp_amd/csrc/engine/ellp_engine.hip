@@ -56,6 +56,7 @@
 #include <vector>
 
 #include "ellp_hip.h"
+#include "ellp_lu_dev.h"
 
 namespace {
 
@@ -334,6 +335,7 @@ struct PriceArgs {
     const double *dp_ldelta, *dp_lside, *dp_d;
     int dp_nrb;
     int dp_maxviol;         // ELLP_FLAG_DUAL_MAX_VIOLATION: the leaving row of largest violation instead of the first violated one
+    const double *rho_ovr;  // dual, certificate above 1,024 rows (ellp_exact.inc): rho from a fresh LU instead of row lr of B^-1
     double *dp_A_N, *dp_A_B, *dp_c_B, *dp_c_N, *dp_x, *dp_dd;
     int64_t *dp_B_index, *dp_N_index;
     uint8_t *dp_Nb;
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256) void k_price(PriceArgs a) {
             return;
         }
         sgn = (ldelta < 0.0) ? -1.0 : 1.0;
-        u2 = reinterpret_cast<const double2 *>((cur ? a.W1 : a.W0) + lr * a.ld);
+        u2 = reinterpret_cast<const double2 *>(a.rho_ovr ? a.rho_ovr : (cur ? a.W1 : a.W0) + lr * a.ld);
     }
     double2 ur[T];
 #pragma unroll
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(256) void k_price_wave(PriceArgs a) {
             return;
         }
         sgn = (ldelta < 0.0) ? -1.0 : 1.0;
-        u2 = reinterpret_cast<const double2 *>((cur ? a.W1 : a.W0) + lr * a.ld);
+        u2 = reinterpret_cast<const double2 *>(a.rho_ovr ? a.rho_ovr : (cur ? a.W1 : a.W0) + lr * a.ld);
     }
     const int gb = a.block0 + (int)blockIdx.x;  // global pricing block
     const int64_t j0 = (int64_t)gb * a.cpb;
@@ -1625,6 +1627,8 @@ struct Update2Args {
     int maxviol;            // dual: ELLP_FLAG_DUAL_MAX_VIOLATION (find_leaving)
     const double *se_gamma; // primal, steepest edge: weights by nonbasic position (null: off)
     double *se_rho;         // ... the pivot row of the inverse this pivot was decided with, kept for the weight update
+    double *se_vpart;       // ... per row block: sum_i d_i * (row i of the inverse FTRAN used) over the block's rows — the partial
+                            // sums of v = B^-T d (k_se_vreduce adds them in block order); null: v comes from k_btran_part / _reduce
     Trace trace;
 };
 
@@ -1811,6 +1815,23 @@ __global__ __launch_bounds__(256) void k_update2(Update2Args a) {
                     const int64_t t = tid + 256 * u;
                     const double2 pv = rho2[t < halfw ? t : 0];
                     pr[u] = t < halfw ? pv : make_double2(0.0, 0.0);
+                }
+                if (MODE == 0 && a.se_vpart) {
+                    // steepest edge: this block's share of v = B^-T d, from the rows of the OLD inverse it holds anyway (the
+                    // separate transposed GEMV re-read all of B^-1: 8 m ld bytes and two launches per iteration)
+                    double2 *vp = reinterpret_cast<double2 *>(a.se_vpart + ((int64_t)blockIdx.x - NBK) * a.ld);
+#pragma unroll
+                    for (int u = 0; u < NR; ++u) {
+                        const int64_t t = tid + 256 * u;
+                        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int k = 0; k < UPD_ROWS; ++k) {
+                            if (!(k < a.rows_per_block && row0 + k < m)) continue;
+                            acc.x = fma(dv[k], wreg[k][u].x, acc.x);
+                            acc.y = fma(dv[k], wreg[k][u].y, acc.y);
+                        }
+                        if (t < halfw) vp[t] = acc;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < UPD_ROWS; ++k) {
@@ -2843,6 +2864,7 @@ __global__ __launch_bounds__(256) void k_rephase(const double *c, const uint8_t 
 #include "ellp_small.inc"
 #include "ellp_mid.inc"
 #include "ellp_se.inc"
+#include "ellp_exact.inc"
 
 }  // namespace
 
@@ -2953,6 +2975,7 @@ struct ellp_engine {
     int dual_maxviol = 0;  // ELLP_FLAG_DUAL_MAX_VIOLATION
     bool se = false;       // ELLP_FLAG_PRIMAL_STEEPEST_EDGE (ellp_se.inc): three launches + one transposed GEMV per iteration
     double *se_gamma = nullptr, *se_rho = nullptr, *se_v = nullptr;
+    double *se_vpart = nullptr;  // per row block of k_update2: its share of v = B^-T d (null: the separate transposed GEMV)
     int64_t unit_columns = 0;  // how many variables have one (diagnostics)
     // 128 < m <= 1024: the same loop with its factors in global memory (ellp_mid.inc); `small` is set as well, so
     // that everything that asks "is there an explicit inverse" keeps working unchanged
@@ -2977,6 +3000,15 @@ struct ellp_engine {
         double obj = 0.0;
     } snap;
     double *inv_out = nullptr;
+    // above 1,024 rows (ellp_exact.inc): terminal statuses are certified by one iteration whose u / rho and d come from a fresh
+    // LU of the basis (no pivot guard, no redo at these sizes)
+    bool cert_large = false;
+    bool luw_ready = false;
+    EllpLuWork luw{};
+    double *ex_rhs = nullptr, *ex_sol = nullptr, *ex_rho = nullptr;
+    int *ex_fail = nullptr;
+    const double *price_rho_ovr = nullptr;  // launch_price<1>: PriceArgs::rho_ovr for the next launch
+    uint64_t hy_uncertified = 0;
     // the LP is a "box problem" — every bound TwoSided or Fixed and b = 0: the shape of DualPhase1's LP (dual_problem.rs:89-131),
     // whose dual objective is minus the dual infeasibility of the original problem, i.e. <= 0 and = 0 at a feasible end
     bool box_problem = false;
@@ -3167,6 +3199,7 @@ void launch_price(ellp_engine *e) {
     a.pp_on = e->pp_P > 1 ? 1 : 0;
     a.vs_row = !(e->opts.flags & ELLP_FLAG_DENSE_PRICING) ? e->vs_row : nullptr;
     a.vs_val = a.vs_row ? e->vs_val : nullptr;
+    a.rho_ovr = MODE == 1 ? e->price_rho_ovr : nullptr;
     if (MODE == 1 && e->dual_fold) {
         a.dp_seq = e->dual_seq;
         a.dp_lrow = e->binfo; a.dp_ldelta = e->bmin; a.dp_lside = e->bmin + e->m; a.dp_d = e->d;
@@ -3240,6 +3273,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.maxviol = e->dual_maxviol;
     a.se_gamma = (MODE == 0 && e->se) ? e->se_gamma : nullptr;
     a.se_rho = (MODE == 0 && e->se) ? e->se_rho : nullptr;
+    a.se_vpart = (MODE == 0 && e->se) ? e->se_vpart : nullptr;
     a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     const dim3 g(e->upd2_blocks + (MODE == 0 ? 2 : 3)), b(256);
     const size_t lds = MODE == 0 ? e->upd_lds : 0;
@@ -3680,7 +3714,7 @@ void launch_primal_iteration(ellp_engine *e) {
         Prof p(e, ELLP_K_FTRAN);
         launch_ftran2<0>(e);
     }
-    if (e->se) {  // v = B^-T d from the inverse this iteration's FTRAN used: the weight update of the NEXT pricing launch
+    if (e->se && !e->se_vpart) {  // v = B^-T d from the inverse this iteration's FTRAN used: the weight update of the NEXT pricing launch
         Prof p(e, ELLP_K_BTRAN);
         BtranArgs a{e->W, e->W2, e->d, e->upart, e->se_v, e->se_v, e->st, e->m, e->ld, e->btran_rows, e->btran_tiles};
         const int64_t half = e->ld >> 1;
@@ -3691,6 +3725,11 @@ void launch_primal_iteration(ellp_engine *e) {
     {
         Prof p(e, ELLP_K_UPDATE);
         launch_update2<0>(e, e->opts.btran_mode == 1 ? 0 : 1);
+    }
+    if (e->se && e->se_vpart) {  // v = the row blocks' partial sums of k_update2, added in block order
+        Prof p(e, ELLP_K_BTRAN);
+        hipLaunchKernelGGL(k_se_vreduce, dim3((unsigned)((e->ld + 63) / 64)), dim3(256), 0, e->stream, e->se_vpart, e->se_v, e->st, e->ld,
+                           e->upd2_blocks);
     }
     e->since_btran += 1;
     e->since_refactor += 1;
@@ -3912,6 +3951,10 @@ void ellp_engine_destroy(ellp_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->luw_ready) {
+        ellp_lu_rows_free(&e->luw);
+        e->luw_ready = false;
+    }
 #ifdef ELLP_DBG_STAMPS
     if (e->h_st && hipMemcpy(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost) == hipSuccess) {
         long long t0 = e->h_st->dbg[0][0][0] ? e->h_st->dbg[0][0][0] : e->h_st->dbg[1][0][0];
@@ -4430,6 +4473,10 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
             (void)hipGetLastError();  // no memory for the factors: the plain explicit-inverse engine
         }
     }
+    // above 1,024 rows (the persistent kernel's limit): terminal statuses certified by an exact-LU iteration (ellp_exact.inc)
+    if (!e->small && !e->hybrid && e->opts.pipeline == 0 && !(e->opts.flags & ELLP_FLAG_NO_CERTIFY) && m > MID_MAX_M && m <= 8192 &&
+        n_N > 0 && e->pp_P <= 1 && !e->se && e->opts.btran_mode == 0 && getenv("ELLP_NO_HYBRID") == nullptr)
+        e->cert_large = true;
     // two launches per primal iteration from m = 1024 (ellp_lagged.inc), or on request
     {
         const int pl = e->opts.pipeline;
@@ -4451,6 +4498,15 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         ECHK(dmalloc(e, &e->se_gamma, (size_t)n_N));
         ECHK(dmalloc(e, &e->se_rho, (size_t)ld));
         ECHK(dmalloc(e, &e->se_v, (size_t)ld));
+        // v = B^-T d accumulated by k_update2's row blocks (their rows of the old inverse are in registers there) where every
+        // row of a block goes through the register path: <= 4 rows per block and NR > 0 (ld <= 4096); otherwise the GEMV
+        if (ld <= 4096 && getenv("ELLP_SE_BTRAN") == nullptr) {
+            if (e->upd2_rows > UPD_ROWS) {
+                e->upd2_rows = UPD_ROWS;
+                e->upd2_blocks = (int)((m + e->upd2_rows - 1) / e->upd2_rows);
+            }
+            ECHK(dmalloc(e, &e->se_vpart, (size_t)((int64_t)e->upd2_blocks * ld)));
+        }
         ECHK(dmalloc(e, &perm, 4));
         ECHK(hipMemsetAsync(e->se_rho, 0, sizeof(double) * (size_t)ld, e->stream));
         ECHK(hipMemsetAsync(e->se_v, 0, sizeof(double) * (size_t)ld, e->stream));
@@ -4786,6 +4842,118 @@ static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errle
     return ELLP_OPTIMAL;
 }
 
+// The certificate above 1,024 rows (ellp_exact.inc): the explicit-inverse loop has reported a terminal status; one iteration
+// is run with u / rho and d = B^-1 a_q from a fresh LU of the basis (dual: x_B recomputed from it first).  Returns as
+// exact_takeover does.
+static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
+    const int s = e->h_st->status;
+    if (!(s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED)) return 0;
+    (void)remaining;  // the loop body that found the status is examined again: no budget is needed
+    auto fail = [&](hipError_t rc) {
+        set_err(errbuf, errlen, "HIP error %s in the certificate of the terminal status", hipGetErrorString(rc));
+        *result = ELLP_ERR_DEVICE;
+        return 2;
+    };
+    hipError_t rc;
+    const int64_t m = e->m, ld = e->ld;
+    if (!e->luw_ready) {
+        if ((rc = ellp_lu_rows_alloc(&e->luw, m)) != hipSuccess) {
+            ellp_lu_rows_free(&e->luw);
+            (void)hipGetLastError();
+            e->cert_large = false;  // no memory for the factors: the status goes out uncertified
+            e->hy_uncertified += 1;
+            return 0;
+        }
+        e->luw_ready = true;
+        if ((rc = dmalloc(e, &e->ex_rhs, (size_t)ld)) != hipSuccess) return fail(rc);
+        if ((rc = dmalloc(e, &e->ex_sol, (size_t)ld)) != hipSuccess) return fail(rc);
+        if ((rc = dmalloc(e, &e->ex_rho, (size_t)ld)) != hipSuccess) return fail(rc);
+        if ((rc = dmalloc(e, &e->ex_fail, 4)) != hipSuccess) return fail(rc);
+        (void)hipMemsetAsync(e->ex_rho, 0, sizeof(double) * (size_t)ld, e->stream);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * m));
+    }
+    // re-arm: the state is complete (a status found by k_ftran_eta comes with that pass's eta update done; one found by a
+    // ratio-test fold comes before anything of its iteration is committed); the loop body that found it is not counted twice
+    DevState ns = *e->h_st;
+    ns.status = ST_RUNNING;
+    ns.nan_flag = 0; ns.tiny = 0; ns.tiny_p = 0; ns.fin = 0; ns.need_rebuild = 0; ns.panic_code = 0;
+    ns.open = 0; ns.pe_valid = 0; ns.mv_pending = 0; ns.usel = 0; ns.usel_next = 0;
+    if (ns.iters > 0) ns.iters -= 1;
+    *e->h_st = ns;
+    if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return fail(rc);
+    if ((rc = hipMemsetAsync(e->ex_fail, 0, sizeof(int), e->stream)) != hipSuccess) return fail(rc);
+    e->lag_open = false;
+    e->dual_open = false;
+    const unsigned gm = (unsigned)((m + 255) / 256), gld = (unsigned)((ld + 255) / 256);
+    hipLaunchKernelGGL(k_rows_from_cols, dim3((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, e->stream, e->A_B, e->luw.M, m, ld);
+    ellp_lu_rows_factor(&e->luw, e->stream);
+    const size_t lds0 = sizeof(double) * (size_t)m, lds1 = 2 * sizeof(double) * (size_t)m;
+    const bool was_lagged = e->lagged, was_fused = e->dual_fused, was_fold = e->dual_fold;
+    if (e->kind == ELLP_ENGINE_PRIMAL) {
+        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds1, e->stream, e->luw.M, e->luw.piv, m, e->c_B, e->ex_sol, 1, e->ex_fail);
+        hipLaunchKernelGGL(k_exact_put_u, dim3(gld), dim3(256), 0, e->stream, e->ex_sol, e->u, m, ld, e->ex_fail);
+        e->lagged = false;
+        launch_price<0>(e);
+        launch_ftran2<0>(e);
+        hipLaunchKernelGGL(k_exact_gather_aq, dim3(gm), dim3(256), 0, e->stream, e->A_N, e->st, m, ld, e->ex_rhs);
+        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_sol, 0, e->ex_fail);
+        ExactLamArgs la{e->ex_sol, e->d, e->lam, e->bidx, e->dpos, e->B_index, e->x, e->lb, e->ub, e->kindv, e->st, m, e->eps, e->ex_fail};
+        hipLaunchKernelGGL(k_exact_relam, dim3(gm), dim3(256), 0, e->stream, la);
+        launch_update2<0>(e, 1);
+        e->lagged = was_lagged;
+    } else {
+        // x_B = A_B^-1 (b - A_N x_N) from the LU (the kernels of launch_resync form the right-hand side)
+        ResyncArgs ra{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
+                      e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles, 1};
+        ra.cols_per_tile = (int)((e->nN + e->btran_tiles - 1) / e->btran_tiles);
+        const int64_t half = ld >> 1;
+        hipLaunchKernelGGL(k_resync_gather, dim3((unsigned)((e->nN + 255) / 256)), dim3(256), 0, e->stream, ra);
+        hipLaunchKernelGGL(k_resync_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0, e->stream, ra);
+        hipLaunchKernelGGL(k_resync_rhs, dim3(gld), dim3(256), 0, e->stream, ra);
+        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->tvec, e->cand, 0, e->ex_fail);
+        hipLaunchKernelGGL(k_resync_apply, dim3(gm), dim3(256), 0, e->stream, ra);
+        launch_dleave(e);
+        hipLaunchKernelGGL(k_exact_unit, dim3(gm), dim3(256), 0, e->stream, e->ex_rhs, m, e->st);
+        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds1, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_rho, 1, e->ex_fail);
+        e->dual_fused = e->dual_fold = false;
+        e->price_rho_ovr = e->ex_rho;
+        e->dual_seq += 1;
+        launch_price<1>(e);
+        launch_ftran2<1>(e);
+        hipLaunchKernelGGL(k_exact_gather_aq, dim3(gm), dim3(256), 0, e->stream, e->A_N, e->st, m, ld, e->ex_rhs);
+        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_sol, 0, e->ex_fail);
+        hipLaunchKernelGGL(k_exact_copy, dim3(gm), dim3(256), 0, e->stream, e->ex_sol, e->d, m, e->st, e->ex_fail);
+        launch_update2<1>(e, 0);
+        e->price_rho_ovr = nullptr;
+        e->dual_fused = was_fused;
+        e->dual_fold = was_fold;
+    }
+    int failed = 0;
+    if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
+    if ((rc = hipMemcpyAsync(&failed, e->ex_fail, sizeof(int), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
+    if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
+    if ((rc = hipGetLastError()) != hipSuccess) return fail(rc);
+    prof_collect(e);
+    const int s2 = e->h_st->status;
+    e->hy_certs += 1;
+    e->hy_exact_iters += 1;
+    if (failed) e->hy_uncertified += 1;  // an exactly singular basis: the iteration ran on the explicit inverse's numbers
+    if (s2 != s) e->hy_disagree += 1;
+    if (getenv("ELLP_HYBRID_DEBUG"))
+        fprintf(stderr, "ellp hybrid: fast status %d at iteration %llu -> exact-LU iteration, status %d%s\n", s,
+                (unsigned long long)ns.iters, s2, failed ? " (LU singular: not certified)" : "");
+    e->u_valid = false;
+    e->since_btran = 0;
+    e->maint_chain = 0;
+    e->enqueued = 0;
+    e->iters_seen = e->h_st->iters;
+    e->need_dleave = false;
+    if (s2 == ST_RUNNING && !e->h_st->tiny) return 1;
+    if (s2 == ST_RUNNING) return 1;  // a maintenance request raised by the iteration: the run loop services it
+    *result = status_message(*e->h_st, errbuf, errlen);
+    return 2;
+}
+
 // Certified hybrid (restated in oracle/ellp_oracle.c, hybrid_run): the explicit-inverse loop has stopped — on a guarded
 // pivot (ST_NEED_EXACT: nothing of that iteration is committed), on a terminal status, or on an error of its own arithmetic
 // (singular rebuild, NaN, an assertion of the reference).  h_st is the drained device state.  The LU-per-iteration kernel
@@ -4795,6 +4963,7 @@ static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errle
 // Returns 0: nothing to do; 1: the loop goes on (status RUNNING, B^-1 rebuilt from the basis k_mid left);
 // 2: the solve has ended, *result holds the status k_mid found (certified, or corrected).
 static int exact_takeover(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
+    if (e->cert_large && e->world == 1 && !e->colshard) return exact_certify_large(e, remaining, result, errbuf, errlen);
     if (!e->hybrid || e->world != 1 || e->colshard) return 0;
     const int s = e->h_st->status;
     const bool guard = s == ST_NEED_EXACT;
@@ -4992,6 +5161,9 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
                 HIPCHK(hipGetLastError());
                 reconcile_counters(e);
                 adopt_fin(e);
+                if (getenv("ELLP_RUN_DEBUG"))
+                    fprintf(stderr, "ellp run (look-ahead): status %d iters %llu tiny %d fin %d need_rebuild %d lr %lld obj %.17g\n", e->h_st->status,
+                            (unsigned long long)e->h_st->iters, e->h_st->tiny, e->h_st->fin, e->h_st->need_rebuild, (long long)e->h_st->lr, e->h_st->obj);
                 const uint64_t done = e->h_st->iters - iters0;
                 remaining = done < max_iters ? max_iters - done : 0;
                 if (service_maintenance_request(e)) continue;  // refreshed; the follow-up runs in the loop below
@@ -5024,6 +5196,9 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
             prof_collect(e);
             reconcile_counters(e);
             adopt_fin(e);
+            if (getenv("ELLP_RUN_DEBUG"))
+                fprintf(stderr, "ellp run (polled): status %d iters %llu tiny %d fin %d need_rebuild %d lr %lld obj %.17g\n", e->h_st->status,
+                        (unsigned long long)e->h_st->iters, e->h_st->tiny, e->h_st->fin, e->h_st->need_rebuild, (long long)e->h_st->lr, e->h_st->obj);
             // iterations that really ran (a maintenance request voids the rest of its batch)
             const uint64_t done = e->h_st->iters - iters0;
             remaining = done < max_iters ? max_iters - done : 0;
@@ -5171,7 +5346,7 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                     dst[21] = e->t_setup;
                     if (cap >= 28) {  // certified hybrid: on?, guarded pivots handed over, terminal statuses examined, of those not
                                       // confirmed, loop bodies run by the exact kernel, rebuilds of B^-1 after a hand-over
-                        dst[22] = e->hybrid ? 1.0 : 0.0;
+                        dst[22] = e->hybrid ? 1.0 : (e->cert_large ? 2.0 : 0.0);  // 2: terminal statuses certified by an exact-LU iteration (m > 1024)
                         dst[23] = (double)e->hy_guards;
                         dst[24] = (double)e->hy_certs;
                         dst[25] = (double)e->hy_disagree;
@@ -5305,7 +5480,7 @@ ellp_status ellp_engine_set_shard(ellp_engine *e, int rank, int world, void *exc
     }
     e->rank = rank;
     e->world = world;
-    if (world > 1) e->hybrid = false;  // certification is for unsharded engines
+    if (world > 1) e->hybrid = e->cert_large = false;  // certification is for unsharded engines
     e->nbs = (e->nblocks + world - 1) / world;
     e->seg = 2 * (int64_t)e->nbs + 2 * (int64_t)e->nbs * e->cpb;
     double *nx = static_cast<double *>(exchange_buffer);  // caller-owned (e.g. a torch tensor) ...
@@ -5351,7 +5526,7 @@ ellp_status ellp_engine_step(ellp_engine *e, int phase, char *errbuf, size_t err
     }
     HIPCHK(hipSetDevice(e->device));
     if (e->nN == 0) return ELLP_OPTIMAL;
-    e->hybrid = false;  // the stepped API drives the plain explicit-inverse engine (no guard: nobody would service its stop)
+    e->hybrid = e->cert_large = false;  // the stepped API drives the plain explicit-inverse engine (no guard: nobody would service its stop)
     if (e->small || !e->w_valid) {
         const ellp_status si = ensure_inverse(e, errbuf, errlen);
         if (si != ELLP_OPTIMAL) return si;
@@ -5822,7 +5997,7 @@ ellp_status ellp_engine_shard_columns(ellp_engine *e, int rank, int world, char 
                              !(getenv("ELLP_SHARD_SPLIT") && getenv("ELLP_SHARD_SPLIT")[0] == '1');
     const ellp_status s0 = ellp_engine_set_shard(e, rank, world, nullptr, errbuf, errlen);  // rank, world, nbs, seg, X
     if (s0 != ELLP_OPTIMAL) return s0;
-    e->hybrid = false;  // certification is for unsharded engines
+    e->hybrid = e->cert_large = false;  // certification is for unsharded engines
     if (keep_lagged) {
         e->lagged = true;
         e->lag_open = false;

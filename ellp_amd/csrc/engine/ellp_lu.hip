@@ -31,6 +31,7 @@
 #include <cstring>
 
 #include "ellp_hip.h"
+#include "ellp_lu_dev.h"
 
 namespace {
 
@@ -190,6 +191,43 @@ void set_err(char *errbuf, size_t len, const char *msg, hipError_t e) {
 }
 
 }  // namespace
+
+// ---- the same factorisation of a DEVICE-RESIDENT square matrix stored by rows (ellp_lu_dev.h): the certificate of the
+// certified hybrid above 1,024 rows (ellp_exact.inc) factors the basis with it.  M (m x m, row r at M + r m) is overwritten
+// by the factors exactly as the oracle's lu_factor_inplace leaves them (L's multipliers below the diagonal, U on and above;
+// rows in pivoted order), piv[i] = the row exchanged with row i at step i, udiag[i] = U_ii.
+hipError_t ellp_lu_rows_alloc(EllpLuWork *w, int64_t m) {
+    memset(w, 0, sizeof(*w));
+    w->m = m;
+    hipError_t rc;
+    const unsigned max_blocks = (unsigned)((m + LU_RPB - 1) / LU_RPB) + 1;
+    if ((rc = hipMalloc(reinterpret_cast<void **>(&w->M), sizeof(double) * (size_t)(m * m))) != hipSuccess) return rc;
+    if ((rc = hipMalloc(reinterpret_cast<void **>(&w->prow), sizeof(double) * (size_t)m)) != hipSuccess) return rc;
+    if ((rc = hipMalloc(reinterpret_cast<void **>(&w->irow), sizeof(double) * (size_t)m)) != hipSuccess) return rc;
+    if ((rc = hipMalloc(reinterpret_cast<void **>(&w->udiag), sizeof(double) * (size_t)m)) != hipSuccess) return rc;
+    if ((rc = hipMalloc(reinterpret_cast<void **>(&w->piv), sizeof(int64_t) * (size_t)m)) != hipSuccess) return rc;
+    if ((rc = hipMalloc(&w->cands, sizeof(LuCand) * (size_t)max_blocks)) != hipSuccess) return rc;
+    if ((rc = hipMalloc(&w->st, sizeof(LuState))) != hipSuccess) return rc;
+    return hipSuccess;
+}
+void ellp_lu_rows_free(EllpLuWork *w) {
+    (void)hipFree(w->M); (void)hipFree(w->prow); (void)hipFree(w->irow); (void)hipFree(w->udiag); (void)hipFree(w->piv);
+    (void)hipFree(w->cands); (void)hipFree(w->st);
+    memset(w, 0, sizeof(*w));
+}
+void ellp_lu_rows_factor(EllpLuWork *w, hipStream_t stream) {
+    const int64_t m = w->m;
+    (void)hipMemsetAsync(w->st, 0, sizeof(LuState), stream);
+    for (int64_t i = -1; i < m; ++i) {
+        const int64_t rows = m - i - 1;
+        const unsigned grid = (unsigned)((rows + LU_RPB - 1) / LU_RPB) + 1;
+        hipLaunchKernelGGL(k_lut_step, dim3(grid), dim3(256), 0, stream, w->M, m, m, i, w->prow, w->irow, static_cast<LuCand *>(w->cands),
+                           static_cast<LuState *>(w->st));
+        if (i + 1 < m)
+            hipLaunchKernelGGL(k_lut_fold, dim3(1), dim3(1024), 0, stream, w->M, m, i + 1, static_cast<const LuCand *>(w->cands), grid, w->prow,
+                               w->irow, static_cast<LuState *>(w->st), w->piv, w->udiag);
+    }
+}
 
 extern "C" ellp_status ellp_hip_lu_transposed(int64_t m, int64_t nv, const double *A, int64_t *pivot_out,
                                               double *udiag_out, int device, char *errbuf, size_t errlen) {

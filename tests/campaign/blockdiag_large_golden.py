@@ -25,6 +25,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import GOLDEN, blockdiag, known_answers, permuted_fixture, read_mps  # noqa: E402
 
 CASES = [("adlittle", 10, 30), ("adlittle", 18, 30), ("blend", 14, 30)]
+# SMALL=1: the three problems of 148-336 rows, 60 orders each, into tests/golden/blockdiag_orders.json (seconds per solve)
+if os.environ.get("SMALL") == "1":
+    CASES = [("adlittle", 3, 60), ("blend", 2, 60), ("adlittle", 6, 60)]
 MAX_ITER = 2000000
 
 
@@ -89,7 +92,7 @@ def main():
                 for mode in ("hybrid", "lu"):
                     jobs.append((name, copies, t, fx, dual, mode))
     jobs.sort(key=lambda j: (j[5] == "lu", j[1]))  # the cheap hybrid runs first
-    path = os.path.join(GOLDEN, "blockdiag_large.json")
+    path = os.path.join(GOLDEN, "blockdiag_orders.json" if os.environ.get("SMALL") == "1" else "blockdiag_large.json")
     res = json.load(open(path)) if os.path.exists(path) else {}
     todo = [j for j in jobs if f"{j[2]}" not in res.get(f"{j[0]}x{j[1]}", {}).get(("dual" if j[4] else "primal") + ":" + j[5], {})]
     print(len(jobs), "jobs,", len(todo), "to do", flush=True)

@@ -35,15 +35,20 @@ def main():
         print(json.dumps(rec), flush=True)
         out["seam"].append(rec)
     import ellp_amd
-    for name, copies, orders, _ in T.API_CASES:
+    for name, copies, orders, orders_dual, _ in T.API_CASES:
         key = f"{name}x{copies}"
         rec = {"primal_ok": 0, "dual_ok": 0, "other": []}
+        # above 1,024 rows (BLEND x 14) the dual runs only the orders of the suite: see the comment at T.API_CASES
+        dual_orders = orders_dual if key == "blendx14" else orders
+        rec["dual_orders"] = dual_orders
         t0 = time.time()
         for trial, fx, want in T._orders(name, copies, orders):
             prob = ellp_amd.Problem.from_fixture(fx)
             for solver, cls in (("primal", ellp_amd.PrimalSimplexSolver), ("dual", ellp_amd.DualSimplexSolver)):
+                if solver == "dual" and trial >= dual_orders:
+                    continue
                 try:
-                    r = cls.new(None).solve(prob.clone())
+                    r = cls.new(400000).solve(prob.clone())
                     ok = r.kind == ellp_amd.SolverResult.Optimal and abs(r.solution.obj() / want - 1.0) < 1e-9
                     if ok:
                         v = T.fixture_violation(fx, r.solution.x())

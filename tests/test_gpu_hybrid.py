@@ -30,7 +30,14 @@ SEAM_CASES = [("adlittle", 3, 60), ("blend", 2, 60), ("adlittle", 6, 60), ("adli
 # (name, copies, orders for the primal, orders for the dual).  The dual at 1,008 rows runs fewer orders in the routine suite: one
 # in three of its phase-1 runs ends within drift distance of the reference's EPS test and is repeated by the exact kernel
 # ("certify or redo", 20 s each at that size); profiles/r04_hybrid_orders.json has all 30.
-API_CASES = [("adlittle", 10, 30, 30), ("adlittle", 18, 30, 8)]
+# BLEND x 14 has 1,036 rows: above the persistent kernel's 1,024 — terminal statuses are certified there by an iteration whose
+# u / rho and B^-1 a_q come from a fresh LU of the basis (ellp_exact.inc); there is NO pivot guard and NO redo at that size, so
+# the path itself is the plain explicit-inverse loop's: 3 of the 30 primal orders end phase 1 with an objective below -EPS
+# (the reference's assert!(obj > -EPS); the oracle itself: 2 of 30, on other orders), and in the dual some orders fall into
+# a basis the explicit inverse cannot hold (order 12: a rebuild of B^-1 after every iteration, 6 ms each, from iteration 608
+# of phase 2 on) — the dual runs the first 8 orders here (all fast), the campaign script says what the others do.
+# Last column: how many reference-rule failures the case may show.
+API_CASES = [("adlittle", 10, 30, 30, 3), ("adlittle", 18, 30, 8, 3), ("blend", 14, 30, 8, 5)]
 
 
 def _E():
@@ -163,8 +170,8 @@ def test_every_order_reaches_the_pinned_optimum_at_the_seam(name, copies, orders
     assert len(excused) <= max(2, orders // 10), excused
 
 
-@pytest.mark.parametrize("name,copies,orders,orders_dual", API_CASES, ids=[f"{n}x{c}" for n, c, _, _ in API_CASES])
-def test_every_order_through_the_user_api(name, copies, orders, orders_dual):
+@pytest.mark.parametrize("name,copies,orders,orders_dual,allowed", API_CASES, ids=[f"{n}x{c}" for n, c, _, _, _ in API_CASES])
+def test_every_order_through_the_user_api(name, copies, orders, orders_dual, allowed):
     """Problem -> PrimalSimplexSolver / DualSimplexSolver ::new(None).solve, default engine options"""
     import ellp_amd
     gold = _golden()
@@ -177,7 +184,7 @@ def test_every_order_through_the_user_api(name, copies, orders, orders_dual):
                 continue
             what = None
             try:
-                r = cls.new(None).solve(prob.clone())
+                r = cls.new(400000).solve(prob.clone())  # a budget far above any of these solves (2-7 thousand iterations)
                 ok = r.kind == ellp_amd.SolverResult.Optimal and abs(r.solution.obj() / want - 1.0) < 1e-9
                 viol = fixture_violation(fx, r.solution.x()) if ok else None
                 ok = ok and viol[0] < 1e-8 and viol[1] < 1e-8  # rows relative to 1 + |rhs|, bounds absolute
@@ -193,7 +200,7 @@ def test_every_order_through_the_user_api(name, copies, orders, orders_dual):
                 (excused if (ref is False or eps_assert) else bad).append((trial, solver, what, ref))
     print(f"{key} through the user API: {orders} + {orders_dual} orders; reference-rule failures: {excused}")
     assert not bad, bad
-    assert len(excused) <= max(2, (orders + orders_dual) // 10), excused
+    assert len(excused) <= allowed, excused
 
 
 def test_guarded_pivot_hands_over_and_back():

@@ -13,11 +13,13 @@ for t in range(orders):
     fx = permuted_fixture(base, rng)
     prob = ellp_amd.Problem.from_fixture(fx)
     try:
-        r = ellp_amd.DualSimplexSolver.new(None).solve(prob)
+        cls = ellp_amd.PrimalSimplexSolver if os.environ.get("SOLVER") == "primal" else ellp_amd.DualSimplexSolver
+        r = cls.new(None).solve(prob)
         ok = r.kind == "optimal" and abs(r.solution.obj() / want - 1) < 1e-9
         what = (r.kind, r.iters)
     except Exception as ex:
         ok, what = False, repr(ex)[:80]
+    print("order", t, ok, what, flush=True)
     if not ok:
         bad.append((t, what))
 print(len(bad), "bad of", orders, bad)
