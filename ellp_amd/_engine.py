@@ -403,7 +403,7 @@ class Engine:
                     rebuild_shortcuts=int(v[20]), t_setup_s=float(v[21]),
                     # certified hybrid: is it on, guarded pivots handed to the exact kernel, terminal statuses
                     # examined, of those not confirmed, loop bodies run by the exact kernel, rebuilds after a hand-over
-                    hybrid=bool(v[22]), certified_by_exact_lu_iteration=(int(v[22]) == 2), hybrid_guards=int(v[23]), hybrid_certs=int(v[24]), hybrid_disagreed=int(v[25]),
+                    hybrid=(int(v[22]) == 1), certified_by_exact_lu_iteration=(int(v[22]) == 2), hybrid_guards=int(v[23]), hybrid_certs=int(v[24]), hybrid_disagreed=int(v[25]),
                     hybrid_exact_iters=int(v[26]), hybrid_rebuilds=int(v[27]), hybrid_redos=int(v[28]))
 
     # ---- sharded / stepped driving (see ellp_amd/dist.py)

@@ -253,3 +253,39 @@ def test_flag_no_certify_is_the_plain_engine():
         assert not eng.counters()["hybrid"]
     finally:
         eng.close()
+
+
+def test_certificate_above_1024_rows_catches_a_false_optimum():
+    """m = 1100 (above the persistent kernel's limit): B^-1 is wiped (test hook: scaled by 0), so the explicit-inverse loop
+    prices with u = 0, sees no candidate in phase 1 and reports Optimal at the starting basis.  The certificate — one iteration
+    with u and B^-1 a_q from a fresh LU of the basis (ellp_exact.inc) — must refuse that and make the pivot the reference's
+    loop makes, five times in a row: the basis after five such iterations is the oracle's, the point too."""
+    E = _E()
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(7, 1100, 2000)
+
+    class V:
+        pass
+    ov = V()
+    for k, val in f.items():
+        setattr(ov, k, val.copy() if hasattr(val, "copy") else val)
+    ov.nB, ov.nN = len(f["B"]), len(f["N"])
+    st_o, it_o, _ = eo.primal_solve_with_initial(ov, 5)
+    assert st_o == eo.MAXITER and it_o == 5
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"])
+    eng = E.Engine(E.ENGINE_PRIMAL, fp, E.default_opts(max_iter=None))
+    try:
+        c0 = eng.counters()
+        assert c0["certified_by_exact_lu_iteration"] and c0["launches_per_iteration"] == 2, c0
+        eng.debug_scale_inverse(0.0)
+        st, stats, msg = eng.run(5)
+        eng.read_point()
+        c = eng.counters()
+    finally:
+        eng.close()
+    assert st == E.MAXITER and stats.iters == 5, (st, stats.iters, msg)
+    assert c["hybrid_certs"] == 5 and c["hybrid_disagreed"] == 5, c
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(fp.N[:fp.nN], ov.N[:ov.nN])
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.x).max()))
+
