@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void k_qr_swap(double *A, int64_t m, int64_t n
     }
     // two candidates closer than the parallel reductions of the fast mode can tell apart (they agree with the host loop's
     // sums to ~1e-14 relative): the host re-runs the factorisation in the exact mode (ellp_hip_qr_transposed)
-    if (blockIdx.x == 0 && tid == 0 && sv >= 0.0 && bv > 0.0 && bv - sv <= 1e-12 * bv) st->near_tie = 1;
+    // (EXACT ties are left to the index rule, as in the host loop: bit-equal candidates are entries no reflection has touched —
+    // the slack entries of a standard form end up as the largest entry of every trailing column, all exactly 1 — or the results of
+    // identical operations on identical data, equal in both modes)
+    if (blockIdx.x == 0 && tid == 0 && sv >= 0.0 && bv > 0.0 && bv - sv > 0.0 && bv - sv <= 1e-12 * bv) st->near_tie = 1;
     const int64_t pj = bj;
     if (blockIdx.x == 0 && tid == 0) {
         st->pj = pj;
@@ -509,7 +512,7 @@ static ellp_status qr_transposed_impl(int64_t m, int64_t nv, const double *A, in
 }
 
 // Fast mode by default; a factorisation in which two pivot candidates came closer than the fast mode's parallel reductions
-// can tell apart (1e-12 relative: exact ties included — the many equal entries of real LPs) is done again in the exact mode,
+// can tell apart (different, but within 1e-12 relative; exact ties go by the index rule in both modes) is done again in the exact mode,
 // whose every number is the host loop's: the pivot order — which standard_form.rs:142-181 turns into the ROW ORDER of the
 // standard form, hence into the basis order and every tie-break downstream — is then the host's and the reference's in
 // every case.  ELLP_QR_EXACT=1: exact from the start; ELLP_QR_EXACT=0: fast without the fall-back (measurements).

@@ -393,7 +393,7 @@ void ellp_engine_destroy(ellp_engine *e);
  * column of A^T (row of A) swapped into position i at step i (the transposition list),
  * rdiag_out[i] = |R_ii|, both of length min(m, nv).  Default: the host loop's steps with norms and dot products reduced in
  * parallel (fast mode; |R_ii| to rounding, reproducible from run to run) — and, if at any step the two best pivot candidates
- * were closer than those reductions can tell apart (1e-12 relative, exact ties included), the factorisation is done again in
+ * were different but closer than those reductions can tell apart (1e-12 relative), the factorisation is done again in
  * the exact mode, in which every floating-point result is bitwise what the host loop of ellp_amd/csrc/host/dense.h
  * (ColPivQR) produces (4x slower): the pivot order is the host loop's in every case.  ELLP_QR_EXACT=1 in the environment:
  * exact from the start; ELLP_QR_EXACT=0: fast without the fall-back (measurements).  device < 0: current device.

@@ -110,8 +110,8 @@ def test_device_qr_is_the_host_loop(name, A, qr_mode):
         np.testing.assert_array_equal(piv_d, piv_h)
         np.testing.assert_array_equal(rd_d, rd_h)  # bitwise
         return
-    if qr_mode == "default" and name in ("ties", "near-ties"):
-        # two candidates within 1e-12 of each other at some step: the default falls back to the exact mode, so the pivot
+    if qr_mode == "default" and name == "near-ties":
+        # two DIFFERENT candidates within 1e-12 of each other at step 0: the default falls back to the exact mode, so the pivot
         # ORDER (the row order of the standard form, standard_form.rs:142-181) is the host loop's to the last position
         np.testing.assert_array_equal(piv_d, piv_h)
         np.testing.assert_array_equal(rd_d, rd_h)
