@@ -3728,7 +3728,7 @@ void launch_primal_iteration(ellp_engine *e) {
     }
     if (e->se && e->se_vpart) {  // v = the row blocks' partial sums of k_update2, added in block order
         Prof p(e, ELLP_K_BTRAN);
-        hipLaunchKernelGGL(k_se_vreduce, dim3((unsigned)((e->ld + 63) / 64)), dim3(256), 0, e->stream, e->se_vpart, e->se_v, e->st, e->ld,
+        hipLaunchKernelGGL(k_se_vreduce, dim3((unsigned)((e->ld + 15) / 16)), dim3(256), 0, e->stream, e->se_vpart, e->se_v, e->st, e->ld,
                            e->upd2_blocks);
     }
     e->since_btran += 1;
