@@ -226,7 +226,7 @@ def pmc_traffic(m, n, solver, dual, which="pricing"):
     return None, (f"no PMC file for the current engine sources ({want}); newest older one: {stale}" if stale else None)
 
 
-def rocprof_avg_us(which, dual):
+def rocprof_avg_us(which, dual, accept=None):
     """average duration of a kernel in a committed rocprofv3 --kernel-trace --stats summary of this command
     (profiles/*default_kernel_stats.csv) — only from a summary whose side file (.meta.json, tools/rocprof_bench.sh) says
     it was taken on the current engine sources"""
@@ -245,7 +245,7 @@ def rocprof_avg_us(which, dual):
             name = row.get("Name") or row.get("KernelName") or ""
             mm = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", name)
             short = mm.group(1) if mm else ""
-            if short and _kernel_matches(short, which, dual):
+            if short and _kernel_matches(short, which, dual) and (accept is None or accept(short)):
                 try:
                     avg_ns = float(row.get("AverageNs") or row.get("Average") or 0.0)
                 except ValueError:
@@ -404,9 +404,11 @@ def roofline_of(meas, m, n, solver, world):
         traffic, src = pmc_traffic(m, n, solver, dual)
     t_us = prof[pk]["avg_us"]
     ach = meas["price_bytes"] / (t_us * 1e-6) / 1e9
-    rp_us, rp_name, rp_file = rocprof_avg_us("pricing", dual) if (world == 1 and (m, n) in ((2000, 5000), (4000, 40000))) else (None, None, None)
-    if rp_name is not None and (m, n) == (4000, 40000) and not rp_name.startswith("k_price2<"):
-        rp_us, rp_name, rp_file = (None, None, None)  # the summary of the default command holds config 3's wave kernel under the same prefix
+    # the summary of the default command holds config 3's, 4's and 5's kernels: config 3 prices with the wave-per-column
+    # kernel, config 5 (A_N far beyond the Infinity Cache) with the block kernel
+    big = (m, n) == (4000, 40000)
+    rp_us, rp_name, rp_file = (rocprof_avg_us("pricing", dual, (lambda k: k.startswith("k_price2<")) if big else (lambda k: "wave" in k))
+                               if (world == 1 and (m, n) in ((2000, 5000), (4000, 40000))) else (None, None, None))
     return {"kernel": "pricing pass of one GPU (k_price*<%d>)" % (1 if dual else 0), "bound": "hbm",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": traffic,
@@ -439,9 +441,8 @@ def roofline_dominant(meas, m, n, solver, world):
     t_us = prof["ftran"]["avg_us"]
     alg, moved = 24.0 * m * ld, 16.0 * m * ld
     traffic, src = pmc_traffic(m, n, solver, dual, "dominant") if world == 1 else (None, None)
-    rp_us, rp_name, rp_file = rocprof_avg_us("dominant", dual) if world == 1 else (None, None, None)
-    if rp_name is not None and (("<8" in rp_name) != (m > 2048)):
-        rp_us, rp_name, rp_file = (None, None, None)  # the other configuration's instantiation
+    rp_us, rp_name, rp_file = (rocprof_avg_us("dominant", dual, lambda k: ("<8" in k) == (m > 2048))  # this configuration's instantiation
+                               if world == 1 else (None, None, None))
     ach = alg / (t_us * 1e-6) / 1e9
     return {"kernel": "k_dual_fu (FTRAN + eta update + x_B / d / y updates)" if dual else "k_ftran_eta (eta update of the previous pivot + FTRAN)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
