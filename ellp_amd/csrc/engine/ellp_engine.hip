@@ -4848,7 +4848,7 @@ static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errle
 static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
     const int s = e->h_st->status;
     if (!(s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED)) return 0;
-    (void)remaining;  // the loop body that found the status is examined again: no budget is needed
+    remaining += 1;  // the loop body that found the status is examined again, not counted twice
     auto fail = [&](hipError_t rc) {
         set_err(errbuf, errlen, "HIP error %s in the certificate of the terminal status", hipGetErrorString(rc));
         *result = ELLP_ERR_DEVICE;
@@ -4885,60 +4885,75 @@ static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *
     e->lag_open = false;
     e->dual_open = false;
     const unsigned gm = (unsigned)((m + 255) / 256), gld = (unsigned)((ld + 255) / 256);
-    hipLaunchKernelGGL(k_rows_from_cols, dim3((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, e->stream, e->A_B, e->luw.M, m, ld);
-    ellp_lu_rows_factor(&e->luw, e->stream);
     const size_t lds0 = sizeof(double) * (size_t)m, lds1 = 2 * sizeof(double) * (size_t)m;
     const bool was_lagged = e->lagged, was_fused = e->dual_fused, was_fold = e->dual_fold;
-    if (e->kind == ELLP_ENGINE_PRIMAL) {
-        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds1, e->stream, e->luw.M, e->luw.piv, m, e->c_B, e->ex_sol, 1, e->ex_fail);
-        hipLaunchKernelGGL(k_exact_put_u, dim3(gld), dim3(256), 0, e->stream, e->ex_sol, e->u, m, ld, e->ex_fail);
-        e->lagged = false;
-        launch_price<0>(e);
-        launch_ftran2<0>(e);
-        hipLaunchKernelGGL(k_exact_gather_aq, dim3(gm), dim3(256), 0, e->stream, e->A_N, e->st, m, ld, e->ex_rhs);
-        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_sol, 0, e->ex_fail);
-        ExactLamArgs la{e->ex_sol, e->d, e->lam, e->bidx, e->dpos, e->B_index, e->x, e->lb, e->ub, e->kindv, e->st, m, e->eps, e->ex_fail};
-        hipLaunchKernelGGL(k_exact_relam, dim3(gm), dim3(256), 0, e->stream, la);
-        launch_update2<0>(e, 1);
-        e->lagged = was_lagged;
-    } else {
-        // x_B = A_B^-1 (b - A_N x_N) from the LU (the kernels of launch_resync form the right-hand side)
-        ResyncArgs ra{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
-                      e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles, 1};
-        ra.cols_per_tile = (int)((e->nN + e->btran_tiles - 1) / e->btran_tiles);
-        const int64_t half = ld >> 1;
-        hipLaunchKernelGGL(k_resync_gather, dim3((unsigned)((e->nN + 255) / 256)), dim3(256), 0, e->stream, ra);
-        hipLaunchKernelGGL(k_resync_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0, e->stream, ra);
-        hipLaunchKernelGGL(k_resync_rhs, dim3(gld), dim3(256), 0, e->stream, ra);
-        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->tvec, e->cand, 0, e->ex_fail);
-        hipLaunchKernelGGL(k_resync_apply, dim3(gm), dim3(256), 0, e->stream, ra);
-        launch_dleave(e);
-        hipLaunchKernelGGL(k_exact_unit, dim3(gm), dim3(256), 0, e->stream, e->ex_rhs, m, e->st);
-        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds1, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_rho, 1, e->ex_fail);
-        e->dual_fused = e->dual_fold = false;
-        e->price_rho_ovr = e->ex_rho;
-        e->dual_seq += 1;
-        launch_price<1>(e);
-        launch_ftran2<1>(e);
-        hipLaunchKernelGGL(k_exact_gather_aq, dim3(gm), dim3(256), 0, e->stream, e->A_N, e->st, m, ld, e->ex_rhs);
-        hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_sol, 0, e->ex_fail);
-        hipLaunchKernelGGL(k_exact_copy, dim3(gm), dim3(256), 0, e->stream, e->ex_sol, e->d, m, e->st, e->ex_fail);
-        launch_update2<1>(e, 0);
-        e->price_rho_ovr = nullptr;
-        e->dual_fused = was_fused;
-        e->dual_fold = was_fold;
-    }
+    // one iteration with u / rho and B^-1 a_q from a fresh LU of the CURRENT basis (enqueued; the state is complete afterwards)
+    auto exact_iteration = [&]() {
+        hipLaunchKernelGGL(k_rows_from_cols, dim3((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, e->stream, e->A_B, e->luw.M, m, ld);
+        ellp_lu_rows_factor(&e->luw, e->stream);
+        if (e->kind == ELLP_ENGINE_PRIMAL) {
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds1, e->stream, e->luw.M, e->luw.piv, m, e->c_B, e->ex_sol, 1, e->ex_fail);
+            hipLaunchKernelGGL(k_exact_put_u, dim3(gld), dim3(256), 0, e->stream, e->ex_sol, e->u, m, ld, e->ex_fail);
+            e->lagged = false;
+            launch_price<0>(e);
+            launch_ftran2<0>(e);
+            hipLaunchKernelGGL(k_exact_gather_aq, dim3(gm), dim3(256), 0, e->stream, e->A_N, e->st, m, ld, e->ex_rhs);
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_sol, 0, e->ex_fail);
+            ExactLamArgs la{e->ex_sol, e->d, e->lam, e->bidx, e->dpos, e->B_index, e->x, e->lb, e->ub, e->kindv, e->st, m, e->eps, e->ex_fail};
+            hipLaunchKernelGGL(k_exact_relam, dim3(gm), dim3(256), 0, e->stream, la);
+            launch_update2<0>(e, 1);
+            e->lagged = was_lagged;
+        } else {
+            // x_B = A_B^-1 (b - A_N x_N) from the LU (the kernels of launch_resync form the right-hand side)
+            ResyncArgs ra{e->A_N, e->W, e->W2, e->b_dev, e->x, e->xg, e->tvec, e->upart, e->cand, e->maxbits, e->B_index,
+                          e->N_index, e->st, e->m, e->ld, e->nN, 0, e->btran_tiles, 1};
+            ra.cols_per_tile = (int)((e->nN + e->btran_tiles - 1) / e->btran_tiles);
+            const int64_t half = ld >> 1;
+            hipLaunchKernelGGL(k_resync_gather, dim3((unsigned)((e->nN + 255) / 256)), dim3(256), 0, e->stream, ra);
+            hipLaunchKernelGGL(k_resync_part, dim3((unsigned)((half + 255) / 256), (unsigned)e->btran_tiles), dim3(256), 0, e->stream, ra);
+            hipLaunchKernelGGL(k_resync_rhs, dim3(gld), dim3(256), 0, e->stream, ra);
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->tvec, e->cand, 0, e->ex_fail);
+            hipLaunchKernelGGL(k_resync_apply, dim3(gm), dim3(256), 0, e->stream, ra);
+            launch_dleave(e);
+            hipLaunchKernelGGL(k_exact_unit, dim3(gm), dim3(256), 0, e->stream, e->ex_rhs, m, e->st);
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds1, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_rho, 1, e->ex_fail);
+            e->dual_fused = e->dual_fold = false;
+            e->price_rho_ovr = e->ex_rho;
+            e->dual_seq += 1;
+            launch_price<1>(e);
+            launch_ftran2<1>(e);
+            hipLaunchKernelGGL(k_exact_gather_aq, dim3(gm), dim3(256), 0, e->stream, e->A_N, e->st, m, ld, e->ex_rhs);
+            hipLaunchKernelGGL(k_lu_solve, dim3(1), dim3(1024), lds0, e->stream, e->luw.M, e->luw.piv, m, e->ex_rhs, e->ex_sol, 0, e->ex_fail);
+            hipLaunchKernelGGL(k_exact_copy, dim3(gm), dim3(256), 0, e->stream, e->ex_sol, e->d, m, e->st, e->ex_fail);
+            launch_update2<1>(e, 0);
+            e->price_rho_ovr = nullptr;
+            e->dual_fused = was_fused;
+            e->dual_fold = was_fold;
+        }
+    };
+    // the first iteration examines the status; if it does NOT confirm it (it pivots), up to exact_K - 1 more follow before the
+    // explicit-inverse loop takes over again — the policy of the certified hybrid (oracle/ellp_oracle.c, hybrid_run)
     int failed = 0;
-    if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
-    if ((rc = hipMemcpyAsync(&failed, e->ex_fail, sizeof(int), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
-    if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
-    if ((rc = hipGetLastError()) != hipSuccess) return fail(rc);
+    uint64_t ran = 0;
+    int s_first = ST_RUNNING;
+    for (int k = 0; k < e->exact_K; ++k) {
+        exact_iteration();
+        if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
+        if ((rc = hipMemcpyAsync(&failed, e->ex_fail, sizeof(int), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
+        if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
+        if ((rc = hipGetLastError()) != hipSuccess) return fail(rc);
+        ran += 1;
+        if (k == 0) s_first = e->h_st->status;
+        if (e->h_st->status != ST_RUNNING || e->h_st->tiny || failed) break;
+        if (k == 0 && remaining <= 1) break;   // the caller's budget
+        if (k > 0 && ran >= remaining) break;
+    }
     prof_collect(e);
     const int s2 = e->h_st->status;
     e->hy_certs += 1;
-    e->hy_exact_iters += 1;
+    e->hy_exact_iters += ran;
     if (failed) e->hy_uncertified += 1;  // an exactly singular basis: the iteration ran on the explicit inverse's numbers
-    if (s2 != s) e->hy_disagree += 1;
+    if (s_first != s) e->hy_disagree += 1;
     if (getenv("ELLP_HYBRID_DEBUG"))
         fprintf(stderr, "ellp hybrid: fast status %d at iteration %llu -> exact-LU iteration, status %d%s\n", s,
                 (unsigned long long)ns.iters, s2, failed ? " (LU singular: not certified)" : "");

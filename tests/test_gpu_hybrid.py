@@ -284,7 +284,9 @@ def test_certificate_above_1024_rows_catches_a_false_optimum():
     finally:
         eng.close()
     assert st == E.MAXITER and stats.iters == 5, (st, stats.iters, msg)
-    assert c["hybrid_certs"] == 5 and c["hybrid_disagreed"] == 5, c
+    # the first certificate refuses the status and — as the policy has it after a disagreement — the exact iterations go on
+    # (up to K = 8, here until the slice is used up): all five loop bodies ran on the fresh LU's numbers
+    assert c["hybrid_certs"] >= 1 and c["hybrid_disagreed"] == c["hybrid_certs"] and c["hybrid_exact_iters"] == 5, c
     np.testing.assert_array_equal(fp.B, ov.B)
     np.testing.assert_array_equal(fp.N[:fp.nN], ov.N[:ov.nN])
     np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.x).max()))
