@@ -276,9 +276,9 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
     nN = fp.nN
     ld = (m + 15) // 16 * 16
 
-    def opts_for(profile, pipeline=None):
+    def opts_for(profile, pipeline=None, flags=0):
         kw = dict(max_iter=None, device=ctx.local_rank, refactor_period=args.refactor_period,
-                  btran_mode=args.btran_mode, poll_interval=args.poll, profile=profile)
+                  btran_mode=args.btran_mode, poll_interval=args.poll, profile=profile, flags=flags)
         if hasattr(E.Opts, "pipeline"):  # ellp_opts.pipeline: 0 engine default, 1 three launches, 2 two
             kw["pipeline"] = (args.pipeline if pipeline is None else pipeline) + 1
         return E.default_opts(**kw)
@@ -335,7 +335,9 @@ def measure(ctx, args, m, n, seed, solver, steps, warmup, profile_steps, long_wi
         same_as_single = None
         if rank == 0:
             fp1 = make_fp()
-            ref = E.Engine(kind, fp1, opts_for(0, pipeline=None if solver == "primal" else 0))  # the sharded loop's kernels
+            # the sharded loop's kernels; flags = 8 (ELLP_FLAG_NO_CERTIFY): a sharded engine runs without the pivot guard and the
+            # certificates of the unsharded default, so the replay does too — the same pivots on both sides by construction
+            ref = E.Engine(kind, fp1, opts_for(0, pipeline=None if solver == "primal" else 0, flags=8))
             ref.run(total_after)
             ref.read_point()
             ref.close()

@@ -305,15 +305,22 @@ SolverResult DualSimplexSolver::solve(Problem prob) const {
         phase_2 = DualPhase2::shell_from_phase1(std::move(phase_1));
         Flat f2 = flatten(phase_2.std_form, phase_2.point.point);
         char err[512] = {0};
-        const ellp_status rs = ellp_engine_dual_rephase(eng.e, phase_2.std_form.c.data(), phase_2.std_form.b.data(),
-                                                        f2.kind.data(), f2.lb.data(), f2.ub.data(), err, sizeof(err));
+        // an engine that runs whole iterations inside one persistent launch (m <= 128, pipeline 3, or a certified-hybrid engine
+        // that has repeated its phase with the exact kernel) keeps no inverse: no hand-off on the device there — asked of
+        // the engine itself (ELLP_TAP_STATE [19] = launches per iteration, 0 for that kind), not inferred from an error code
+        double tapv[20] = {0};
+        const bool has_inverse = ellp_engine_tap(eng.e, ELLP_TAP_STATE, tapv, 20) >= 20 && tapv[19] != 0.0;
+        const ellp_status rs = has_inverse ? ellp_engine_dual_rephase(eng.e, phase_2.std_form.c.data(), phase_2.std_form.b.data(),
+                                                                      f2.kind.data(), f2.lb.data(), f2.ub.data(), err, sizeof(err))
+                                           : ELLP_ERR_ARG;
         if (rs == ELLP_OPTIMAL) {
             s2 = run_resident_dual(eng.e, max_iter_, f2, phase_2.point, &res.iters_phase2);
-        } else if (rs == ELLP_ERR_ARG || rs == ELLP_ERR_PANIC) {
-            // no hand-off on this engine (the LU-per-iteration kind keeps no inverse), or one of the reference's EPS
+        } else if (!has_inverse || rs == ELLP_ERR_PANIC) {
+            // no hand-off on this engine, or one of the reference's EPS
             // assertions on the sign of d tripped on the device's inverse, which is not the fresh LU the reference
             // takes (dual_problem.rs:275-284): do the hand-off as the reference does, on the host — if the assertion
-            // is the reference's own it fires again there, as the panic it is
+            // is the reference's own it fires again there, as the panic it is.  Any other error of the hand-off (a device
+            // error, bad arguments) is reported, not retried
             ellp_engine_destroy(eng.e);
             eng.e = nullptr;
             phase_2.point_on_host();
