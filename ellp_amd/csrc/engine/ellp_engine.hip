@@ -5253,7 +5253,9 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     // start of the phase by the LU-per-iteration kernel alone: from there on the engine IS the reference's loop, bit for bit.
     if (result == ELLP_OPTIMAL && e->hybrid && e->snap.valid && e->world == 1) {
         double det[3] = {0.0, 0.0, 0.0};
-        if (!end_point_ok(e, det)) {
+        bool ok = end_point_ok(e, det);
+        if (getenv("ELLP_FORCE_REDO")) ok = false;  // tests: the redo path itself (snapshot, restore, the exact kernel from the start)
+        if (!ok) {
             if (getenv("ELLP_HYBRID_DEBUG"))
                 fprintf(stderr, "ellp hybrid: end point violates an invariant (x %.3e, d %.3e, objective %.17g against the carried %.17g): redo\n",
                         det[0], det[1], det[2], e->h_st->obj);

@@ -341,3 +341,37 @@ def test_pivot_guard_above_1024_rows(which):
     else:
         assert np.isfinite(fp.x).all() and np.isfinite(fp.d).all()
 
+
+@pytest.mark.parametrize("which", ["primal", "dual"])
+def test_a_redone_solve_is_the_oracles_bit_for_bit(which):
+    """certify or redo, the redo itself (forced: ELLP_FORCE_REDO): after the hybrid has ended phase 1 of ADLITTLE x 3 the start of
+    the phase is restored from the snapshot — index sets, point, duals, the columns back in their places — and the LU-per-
+    iteration kernel repeats the phase alone: status, iteration count, basis and every bit of x (y, d) are the oracle's, as on
+    `pipeline = 3`"""
+    from test_gpu_small import assert_identical
+    E = _E()
+    trial, fx, _ = next(_orders("adlittle", 3, 1))
+    prob = eo.Problem.from_fixture(fx)
+    p1, err = (eo.primal_phase1 if which == "primal" else eo.dual_phase1)(prob)
+    v = p1.view()
+    ov = v.copy()
+    st_o, it_o, err_o = (eo.primal_solve_with_initial if which == "primal" else eo.dual_solve_with_initial)(ov, 200000)
+    fp = flat(v)
+    os.environ["ELLP_FORCE_REDO"] = "1"
+    try:
+        eng = E.Engine(E.ENGINE_PRIMAL if which == "primal" else E.ENGINE_DUAL, fp, E.default_opts(max_iter=200000))
+        try:
+            assert eng.counters()["hybrid"]
+            st, stats, msg = eng.run(200000)
+            eng.read_point()
+            c = eng.counters()
+        finally:
+            eng.close()
+    finally:
+        del os.environ["ELLP_FORCE_REDO"]
+    if st_o == eo.OPTIMAL:
+        assert c["hybrid_redos"] == 1, c
+        assert_identical(which, ov, st_o, it_o, err_o, fp, st, stats, msg, which)
+    else:
+        assert st == st_o, (st, st_o, msg)
+
