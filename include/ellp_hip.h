@@ -76,7 +76,8 @@ typedef struct ellp_opts {
     int32_t pipeline;        /* launch structure of an iteration: 0 = engine default by size — m <= 128: 3; 128 < m <= 1024: the
                                 CERTIFIED HYBRID: 1 with a pivot guard, every terminal status and every guarded iteration
                                 re-examined by the LU-per-iteration kernel of 3 from the same arrays (DESIGN.md §3.1c;
-                                ELLP_FLAG_NO_CERTIFY: plain 1 / 2 by size); m > 1024: 2 —,
+                                ELLP_FLAG_NO_CERTIFY: plain 1 / 2 by size); m > 1024: 2 with the same guard in its kernels'
+                                prologues, refused iterations and terminal statuses run on a fresh LU of the basis (§3.1d) —,
                                 1 = three launches (pricing | FTRAN | eta update), 2 = two bandwidth
                                 passes (primal: pricing | eta update of the previous pivot fused with this iteration's
                                 FTRAN; dual: pricing | FTRAN fused with this iteration's eta update, + a closing block),
@@ -105,7 +106,10 @@ typedef struct ellp_opts {
                                 three-launch explicit-inverse engine at every size, with the reactive tiny-pivot maintenance
                                 on.  Meant for RESIDENT solves (both phases on one engine, ellp_engine_rephase): a second
                                 engine created with this flag at phase 1's end basis broke down at config 5's size (4000 x
-                                40000) — the ratio test has no pivot-size safeguard, as the reference's has none */
+                                40000) — the ratio test has no pivot-size safeguard, as the reference's has none
+                                bit 3 (ELLP_FLAG_NO_CERTIFY): with pipeline 0, the plain explicit-inverse engine above 128 rows — no
+                                pivot guard, no certificate behind a terminal status, no repeated solve (measurements, and the
+                                replay side of a sharded run's self-check: sharded engines run without them) */
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */
@@ -211,7 +215,14 @@ ellp_status ellp_engine_create_primal_phase1(
 ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stats,
                             char *errbuf, size_t errbuf_len);
 
-/* ellp_engine_run(e, K) runs up to K loop bodies.  On the two-launch primal pipeline (m >= 384) a slice leaves the
+/* Certified endings (pipeline 0, m > 128): a status Optimal / Infeasible / Unbounded that ellp_engine_run
+ * (and the one-shot solve_with_initial entry points) return has been decided by the reference's arithmetic on a fresh LU of the
+ * final basis.  Between 129 and 1,024 rows a solve that ends Optimal on a point violating an invariant of the reference's loop by
+ * more than EPS is repeated from the arrays the phase started with by the LU-per-iteration kernel alone; ellp_stats.iters is then
+ * the repeated solve's count, and the engine keeps running on that kernel (no resident inverse: ellp_engine_dual_rephase returns
+ * ELLP_ERR_ARG, as on any engine of that kind).
+ *
+ * ellp_engine_run(e, K) runs up to K loop bodies.  On the two-launch primal pipeline (m >= 384) a slice leaves the
  * ratio test of its last iteration to the next slice's first kernel; when the slice spends the caller's whole budget
  * (ellp_opts.max_iter loop bodies since the engine was made or re-phased) that iteration is completed before the
  * status is taken, so that — as in the reference, which runs max_iter FULL loop bodies (primal…:162-202) — an
