@@ -23,3 +23,10 @@ for t in range(orders):
     if not ok:
         bad.append((t, what))
 print(len(bad), "bad of", orders, bad)
+import json
+out = os.path.join("/root/repo" if os.path.isdir("/root/repo") else ".", "gpurun_out")
+os.makedirs(out, exist_ok=True)
+solver = os.environ.get("SOLVER", "dual")
+json.dump({"problem": f"{name}x{copies}", "solver": solver, "orders": orders, "at_the_pinned_optimum": orders - len(bad),
+           "others": [{"trial": t, "what": str(w)[:120]} for t, w in bad]},
+          open(os.path.join(out, f"api_orders_{name}x{copies}_{solver}.json"), "w"))
