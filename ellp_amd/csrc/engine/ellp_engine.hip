@@ -2961,6 +2961,7 @@ struct ellp_engine {
     // small LPs (m <= 128): the reference's LU-per-iteration loop in one persistent workgroup (ellp_small.inc)
     bool small = false;      // run() uses k_small
     bool w_valid = true;     // the explicit inverse W (not kept by k_small) matches A_B
+    bool exact_large_only = false;  // after a redo above 1,024 rows: every loop body on a fresh LU (run_exact_large), until the next phase
     size_t small_lds = 0;
     int pp_P = 0;            // partial pricing: number of segments (<= 1: off)
     int64_t pp_S = 0;        // positions per segment
@@ -4778,8 +4779,8 @@ static bool end_point_ok(ellp_engine *e, double *detail3) {
     return true;
 }
 
-// back to the start of the phase, and from now on the LU-per-iteration kernel alone (ellp_mid.inc)
-static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errlen) {
+// back to the start of the phase, and from now on the LU-per-iteration kernel alone (ellp_mid.inc; `large`: run_exact_large)
+static ellp_status redo_from_snapshot(ellp_engine *e, bool large, char *errbuf, size_t errlen) {
     const auto &sn = e->snap;
     const int64_t m = e->m, nN = e->nN, ld = e->ld;
     std::vector<int64_t> B((size_t)m), N((size_t)nN), where((size_t)e->n, INT64_MIN), src((size_t)(m + nN));
@@ -4833,12 +4834,24 @@ static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errle
     if (e->trace_len > 0) RCHK(hipMemsetAsync(e->trace_it, 0, sizeof(unsigned long long) * (size_t)e->trace_len, e->stream));
     RCHK(done(hipSuccess));
 #undef RCHK
-    e->hybrid = false;
-    e->small = true;
-    e->mid = true;
-    e->w_valid = false;
-    e->lagged = false;
-    e->dual_fused = e->dual_fold = false;
+    if (large) {
+        // above 1,024 rows the exact loop is run_exact_large; the explicit inverse follows the restored basis (the exact
+        // iterations keep updating it, and the next phase's fast loop starts from it)
+        e->exact_large_only = true;
+        launch_refactor(e);
+        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        prof_collect(e);
+        e->hy_rebuilds += 1;
+        if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    } else {
+        e->hybrid = false;
+        e->small = true;
+        e->mid = true;
+        e->w_valid = false;
+        e->lagged = false;
+        e->dual_fused = e->dual_fold = false;
+    }
     e->lag_open = e->dual_open = false;
     e->u_valid = false;
     e->need_dleave = true;
@@ -4850,56 +4863,13 @@ static ellp_status redo_from_snapshot(ellp_engine *e, char *errbuf, size_t errle
     return ELLP_OPTIMAL;
 }
 
-// The certificate above 1,024 rows (ellp_exact.inc): the explicit-inverse loop has reported a terminal status; one iteration
-// is run with u / rho and d = B^-1 a_q from a fresh LU of the basis (dual: x_B recomputed from it first).  Returns as
-// exact_takeover does.
-static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
-    const int s = e->h_st->status;
-    const bool guard = s == ST_NEED_EXACT;  // a refused pivot: nothing of that iteration is committed or counted
-    if (!(guard || s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED)) return 0;
-    if (guard && remaining == 0) return 0;  // the slice is used up: the next one starts here
-    if (!guard) remaining += 1;  // the loop body that found the status is examined again, not counted twice
-    auto fail = [&](hipError_t rc) {
-        set_err(errbuf, errlen, "HIP error %s in the certificate of the terminal status", hipGetErrorString(rc));
-        *result = ELLP_ERR_DEVICE;
-        return 2;
-    };
-    hipError_t rc;
+// One iteration with u / rho and B^-1 a_q from a fresh LU of the CURRENT basis (ellp_exact.inc), enqueued; the state is complete
+// afterwards.  The workspace must be there (exact_workspace) and the caller has switched the pivot guard off (guard_off).
+static void enqueue_exact_iteration(ellp_engine *e) {
     const int64_t m = e->m, ld = e->ld;
-    if (!e->luw_ready) {
-        if ((rc = ellp_lu_rows_alloc(&e->luw, m)) != hipSuccess) {
-            ellp_lu_rows_free(&e->luw);
-            (void)hipGetLastError();
-            e->cert_large = false;  // no memory for the factors: the status goes out uncertified
-            e->hy_uncertified += 1;
-            return 0;
-        }
-        e->luw_ready = true;
-        if ((rc = dmalloc(e, &e->ex_rhs, (size_t)ld)) != hipSuccess) return fail(rc);
-        if ((rc = dmalloc(e, &e->ex_sol, (size_t)ld)) != hipSuccess) return fail(rc);
-        if ((rc = dmalloc(e, &e->ex_rho, (size_t)ld)) != hipSuccess) return fail(rc);
-        if ((rc = dmalloc(e, &e->ex_fail, 4)) != hipSuccess) return fail(rc);
-        (void)hipMemsetAsync(e->ex_rho, 0, sizeof(double) * (size_t)ld, e->stream);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * m));
-    }
-    // re-arm: the state is complete (a status found by k_ftran_eta comes with that pass's eta update done; one found by a
-    // ratio-test fold comes before anything of its iteration is committed); the loop body that found it is not counted twice
-    DevState ns = *e->h_st;
-    ns.status = ST_RUNNING;
-    ns.nan_flag = 0; ns.tiny = 0; ns.tiny_p = 0; ns.fin = 0; ns.need_rebuild = 0; ns.panic_code = 0;
-    ns.open = 0; ns.pe_valid = 0; ns.mv_pending = 0; ns.usel = 0; ns.usel_next = 0;
-    if (!guard && ns.iters > 0) ns.iters -= 1;
-    *e->h_st = ns;
-    if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return fail(rc);
-    if ((rc = hipMemsetAsync(e->ex_fail, 0, sizeof(int), e->stream)) != hipSuccess) return fail(rc);
-    e->guard_off = true;
-    e->lag_open = false;
-    e->dual_open = false;
     const unsigned gm = (unsigned)((m + 255) / 256), gld = (unsigned)((ld + 255) / 256);
     const size_t lds0 = sizeof(double) * (size_t)m, lds1 = 2 * sizeof(double) * (size_t)m;
     const bool was_lagged = e->lagged, was_fused = e->dual_fused, was_fold = e->dual_fold;
-    // one iteration with u / rho and B^-1 a_q from a fresh LU of the CURRENT basis (enqueued; the state is complete afterwards)
-    auto exact_iteration = [&]() {
         hipLaunchKernelGGL(k_rows_from_cols, dim3((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32)), dim3(256), 0, e->stream, e->A_B, e->luw.M, m, ld);
         ellp_lu_rows_factor(&e->luw, e->stream);
         if (e->kind == ELLP_ENGINE_PRIMAL) {
@@ -4941,14 +4911,132 @@ static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *
             e->dual_fused = was_fused;
             e->dual_fold = was_fold;
         }
+}
+
+// the LU workspace and the vectors of the exact iteration (allocated at the first use)
+static hipError_t exact_workspace(ellp_engine *e) {
+    if (e->luw_ready) return hipSuccess;
+    const int64_t m = e->m, ld = e->ld;
+    hipError_t rc;
+    if ((rc = ellp_lu_rows_alloc(&e->luw, m)) != hipSuccess) {
+        ellp_lu_rows_free(&e->luw);
+        (void)hipGetLastError();
+        return rc;
+    }
+    e->luw_ready = true;
+    if ((rc = dmalloc(e, &e->ex_rhs, (size_t)ld)) != hipSuccess) return rc;
+    if ((rc = dmalloc(e, &e->ex_sol, (size_t)ld)) != hipSuccess) return rc;
+    if ((rc = dmalloc(e, &e->ex_rho, (size_t)ld)) != hipSuccess) return rc;
+    if ((rc = dmalloc(e, &e->ex_fail, 4)) != hipSuccess) return rc;
+    (void)hipMemsetAsync(e->ex_rho, 0, sizeof(double) * (size_t)ld, e->stream);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * m));
+    return hipSuccess;
+}
+
+// "certify or redo" above 1,024 rows: after a redo every loop body runs on a fresh LU (ellp_engine::exact_large_only) — the
+// reference's LU-per-iteration loop on all CUs instead of in one workgroup: an LU (2 m launches) and four solves per iteration,
+// 20-40 ms at 1,000-2,000 rows; the explicit inverse is still updated along (a later phase goes back to the fast loop).
+static ellp_status run_exact_large(ellp_engine *e, uint64_t max_iters, char *errbuf, size_t errlen) {
+    HIPCHK(exact_workspace(e));
+    HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (e->h_st->status != ST_RUNNING) return status_message(*e->h_st, errbuf, errlen);
+    const uint64_t iters0 = e->h_st->iters;
+    e->lag_open = e->dual_open = false;
+    e->guard_off = true;
+    ellp_status result = ELLP_MAXITER;
+    while (e->h_st->iters - iters0 < max_iters) {
+        HIPCHK(hipMemsetAsync(e->ex_fail, 0, sizeof(int), e->stream));
+        enqueue_exact_iteration(e);
+        int failed = 0;
+        HIPCHK(hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(&failed, e->ex_fail, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipGetLastError());
+        prof_collect(e);
+        if (failed) {  // a zero on U's diagonal: the reference's unwrap() on None in BTRAN / FTRAN
+            set_err(errbuf, errlen, "unwrap() on None: the basis is exactly singular");
+            result = ELLP_ERR_PANIC;
+            break;
+        }
+        if (e->h_st->tiny) {  // raised by the update kernel for the explicit inverse's sake: nothing to maintain here
+            static const int32_t zero = 0;
+            (void)hipMemcpyAsync(&e->st->tiny, &zero, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+            e->h_st->tiny = 0;
+        }
+        if (e->h_st->status != ST_RUNNING) {
+            result = status_message(*e->h_st, errbuf, errlen);
+            break;
+        }
+    }
+    e->guard_off = false;
+    e->u_valid = false;
+    e->enqueued = 0;
+    e->iters_seen = e->h_st->iters;
+    e->hy_exact_iters += e->h_st->iters - iters0;
+    e->need_dleave = true;
+    if (result != ELLP_MAXITER && e->h_st->status != ST_RUNNING) {
+        // the solve has ended: the explicit inverse, updated along through pivots no guard has looked at, is rebuilt from
+        // the final basis (a phase hand-off and the dual point of read_point read it)
+        static const int32_t running = ST_RUNNING;
+        static int32_t keep;
+        keep = e->h_st->status;
+        (void)hipMemcpyAsync(&e->st->status, &running, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        launch_refactor(e);
+        e->hy_rebuilds += 1;
+        DevState after;
+        HIPCHK(hipMemcpyAsync(&after, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        prof_collect(e);
+        if (after.status != ST_RUNNING) e->w_valid = false;
+        e->h_st->cur = after.cur;
+        (void)hipMemcpyAsync(&e->st->status, &keep, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        (void)hipMemcpyAsync(&e->st->panic_code, &e->h_st->panic_code, sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        (void)hipStreamSynchronize(e->stream);
+    }
+    return result;
+}
+
+// The certificate above 1,024 rows (ellp_exact.inc): the explicit-inverse loop has reported a terminal status; one iteration
+// is run with u / rho and d = B^-1 a_q from a fresh LU of the basis (dual: x_B recomputed from it first).  Returns as
+// exact_takeover does.
+static int exact_certify_large(ellp_engine *e, uint64_t remaining, ellp_status *result, char *errbuf, size_t errlen) {
+    const int s = e->h_st->status;
+    const bool guard = s == ST_NEED_EXACT;  // a refused pivot: nothing of that iteration is committed or counted
+    if (!(guard || s == ELLP_OPTIMAL || s == ELLP_INFEASIBLE || s == ELLP_UNBOUNDED)) return 0;
+    if (guard && remaining == 0) return 0;  // the slice is used up: the next one starts here
+    if (!guard) remaining += 1;  // the loop body that found the status is examined again, not counted twice
+    auto fail = [&](hipError_t rc) {
+        set_err(errbuf, errlen, "HIP error %s in the certificate of the terminal status", hipGetErrorString(rc));
+        *result = ELLP_ERR_DEVICE;
+        return 2;
     };
+    hipError_t rc;
+    if ((rc = exact_workspace(e)) != hipSuccess) {
+        e->cert_large = false;  // no memory for the factors: the status goes out uncertified
+        e->hy_uncertified += 1;
+        return 0;
+    }
+    // re-arm: the state is complete (a status found by k_ftran_eta comes with that pass's eta update done; one found by a
+    // ratio-test fold comes before anything of its iteration is committed); the loop body that found it is not counted twice
+    DevState ns = *e->h_st;
+    ns.status = ST_RUNNING;
+    ns.nan_flag = 0; ns.tiny = 0; ns.tiny_p = 0; ns.fin = 0; ns.need_rebuild = 0; ns.panic_code = 0;
+    ns.open = 0; ns.pe_valid = 0; ns.mv_pending = 0; ns.usel = 0; ns.usel_next = 0;
+    if (!guard && ns.iters > 0) ns.iters -= 1;
+    *e->h_st = ns;
+    if ((rc = hipMemcpyAsync(e->st, e->h_st, sizeof(DevState), hipMemcpyHostToDevice, e->stream)) != hipSuccess) return fail(rc);
+    if ((rc = hipMemsetAsync(e->ex_fail, 0, sizeof(int), e->stream)) != hipSuccess) return fail(rc);
+    e->guard_off = true;
+    e->lag_open = false;
+    e->dual_open = false;
     // the first iteration examines the status; if it does NOT confirm it (it pivots), up to exact_K - 1 more follow before the
     // explicit-inverse loop takes over again — the policy of the certified hybrid (oracle/ellp_oracle.c, hybrid_run)
     int failed = 0;
     uint64_t ran = 0;
     int s_first = ST_RUNNING;
     for (int k = 0; k < e->exact_K; ++k) {
-        exact_iteration();
+        enqueue_exact_iteration(e);
         if ((rc = hipMemcpyAsync(e->h_st, e->st, sizeof(DevState), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
         if ((rc = hipMemcpyAsync(&failed, e->ex_fail, sizeof(int), hipMemcpyDeviceToHost, e->stream)) != hipSuccess) return fail(rc);
         if ((rc = hipStreamSynchronize(e->stream)) != hipSuccess) return fail(rc);
@@ -5090,7 +5178,7 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     int64_t period = e->refactor_period;
     if (period <= 0) period = default_period(e);
     ellp_status result = ELLP_MAXITER;
-    if (e->hybrid && !e->snap.valid && e->world == 1 && !e->colshard && e->nN > 0 && getenv("ELLP_NO_REDO") == nullptr) {
+    if ((e->hybrid || e->cert_large) && !e->snap.valid && e->world == 1 && !e->colshard && e->nN > 0 && getenv("ELLP_NO_REDO") == nullptr) {
         launch_flush(e);
         HIPCHK(take_snapshot(e));  // the start of the phase (certify or redo, see end_point_ok)
     }
@@ -5098,6 +5186,8 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         result = ELLP_OPTIMAL;  // primal…:149-151 / dual…:175-177
     } else if (e->small && e->world == 1) {
         result = run_small(e, max_iters, errbuf, errlen);
+    } else if (e->exact_large_only && e->world == 1 && !e->colshard) {
+        result = run_exact_large(e, max_iters, errbuf, errlen);
     } else {
         uint64_t remaining = max_iters;
         if (e->colshard) return run_colsharded(e, max_iters, stats, errbuf, errlen);
@@ -5251,15 +5341,40 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
     // the caller's next test on that point (the phase-1 objective against EPS, primal…:42-50 / dual…:45-50; the assertions of
     // DualPhase2::from, dual_problem.rs:293-310) would fail where the reference's own arithmetic passes — is repeated from the
     // start of the phase by the LU-per-iteration kernel alone: from there on the engine IS the reference's loop, bit for bit.
-    if (result == ELLP_OPTIMAL && e->hybrid && e->snap.valid && e->world == 1) {
+    if (result == ELLP_OPTIMAL && (e->hybrid || (e->cert_large && !e->exact_large_only)) && e->snap.valid && e->world == 1) {
         double det[3] = {0.0, 0.0, 0.0};
         bool ok = end_point_ok(e, det);
         if (getenv("ELLP_FORCE_REDO")) ok = false;  // tests: the redo path itself (snapshot, restore, the exact kernel from the start)
-        if (!ok) {
+        const bool large = !e->hybrid;
+        if (!ok && large) {
+            // Above 1,024 rows the exact loop costs an LU of 2 m launches and four solves of m steps per iteration (about
+            // 18 us x m): the redo is taken when the iterations this phase needed, at that price, stay within
+            // ELLP_REDO_MAX_SECONDS (default 900 — a 1,850-row phase of 3,000 iterations: 100 s; config 3's 600,000: never);
+            // otherwise the point goes out as it is, counted as uncertified (ELLP_TAP_STATE).
+            static const double cap = [] {
+                const char *v = getenv("ELLP_REDO_MAX_SECONDS");
+                return v && v[0] ? atof(v) : 900.0;
+            }();
+            const double est = (double)e->h_st->iters * 18e-6 * (double)e->m;
+            if (est > cap) {
+                if (getenv("ELLP_HYBRID_DEBUG"))
+                    fprintf(stderr, "ellp hybrid: end point violates an invariant (x %.3e, d %.3e); a redo would take about %.0f s: not done\n", det[0], det[1], est);
+                e->hy_uncertified += 1;
+                ok = true;
+            }
+        }
+        if (!ok && large) {
+            if (getenv("ELLP_HYBRID_DEBUG"))
+                fprintf(stderr, "ellp hybrid: end point violates an invariant (x %.3e, d %.3e, objective %.17g): redo on fresh LUs\n", det[0], det[1], det[2]);
+            const ellp_status rs = redo_from_snapshot(e, true, errbuf, errlen);
+            if (rs != ELLP_OPTIMAL) return rs;
+            result = run_exact_large(e, e->opts.max_iter, errbuf, errlen);
+            e->obj_fresh = false;
+        } else if (!ok) {
             if (getenv("ELLP_HYBRID_DEBUG"))
                 fprintf(stderr, "ellp hybrid: end point violates an invariant (x %.3e, d %.3e, objective %.17g against the carried %.17g): redo\n",
                         det[0], det[1], det[2], e->h_st->obj);
-            const ellp_status rs = redo_from_snapshot(e, errbuf, errlen);
+            const ellp_status rs = redo_from_snapshot(e, false, errbuf, errlen);
             if (rs != ELLP_OPTIMAL) return rs;
             result = run_small(e, e->opts.max_iter, errbuf, errlen);
             e->obj_fresh = false;
@@ -5700,6 +5815,7 @@ ellp_status ellp_engine_rephase(ellp_engine *e, const double *c, const uint8_t *
     e->enqueued = 0;
     e->iters_seen = 0;
     e->snap.valid = false;  // a new phase starts here
+    e->exact_large_only = false;  // ... in the fast loop again
     return ELLP_OPTIMAL;
 }
 
@@ -5852,6 +5968,7 @@ ellp_status ellp_engine_dual_rephase(ellp_engine *e, const double *c, const doub
     e->enqueued = 0;
     e->iters_seen = 0;
     e->snap.valid = false;  // a new phase starts here
+    e->exact_large_only = false;  // ... in the fast loop again
     {
         bool box = true;
         for (int64_t i = 0; i < n_c && box; ++i) box = bound_kind[i] == ELLP_BOUND_TWOSIDED || bound_kind[i] == ELLP_BOUND_FIXED;

@@ -375,3 +375,63 @@ def test_a_redone_solve_is_the_oracles_bit_for_bit(which):
     else:
         assert st == st_o, (st, st_o, msg)
 
+
+
+def _quick_primal_start(seed, m, n, k):
+    """primal_phase1_flat with the slack basis on every row but the first k (x_slack = b_i > 0, the artificial nonbasic at 0):
+    a basic feasible start of the same phase-1 problem that is a few hundred pivots from its end instead of 5 m"""
+    from ellp_amd import synth
+    f = synth.primal_phase1_flat(seed, m, n)
+    ntot = n + m
+    B, N, x = f["B"].copy(), f["N"].copy(), f["x"].copy()
+    for i in range(k, m):
+        s, a = n + m - 1 - i, ntot + i
+        B[i] = s
+        N[np.where(N == s)[0][0]] = a
+        x[s], x[a] = f["b"][i], 0.0
+    f.update(B=B, N=N, x=x)
+    return f
+
+
+@pytest.mark.parametrize("which", ["primal", "dual"])
+def test_a_redone_solve_above_1024_rows_follows_the_oracle(which):
+    """certify or redo above 1,024 rows (forced: ELLP_FORCE_REDO), m = 1100: the phase is restored from the snapshot and repeated
+    with EVERY loop body on a fresh LU (run_exact_large: ellp_lu.hip's factorisation + k_lu_solve, the engine's bandwidth
+    kernels fed the exact u / rho and B^-1 a_q) — the reference's loop on all CUs.  Status, iteration count and basis are the
+    oracle's; x (y, d) to 1e-11: the L^T solve sums in another order (ellp_exact.inc), the one place this path is not the
+    oracle's arithmetic bit for bit."""
+    E = _E()
+    from ellp_amd import synth
+    m = 1100
+    f = _quick_primal_start(9, m, 40, 5) if which == "primal" else synth.dual_start_flat(9, m, 40)
+
+    class V:
+        pass
+    ov = V()
+    for k, val in f.items():
+        setattr(ov, k, val.copy() if hasattr(val, "copy") else val)
+    ov.nB, ov.nN = len(f["B"]), len(f["N"])
+    st_o, it_o, _ = (eo.primal_solve_with_initial if which == "primal" else eo.dual_solve_with_initial)(ov, 100000)
+    assert st_o == eo.OPTIMAL and 100 < it_o < 1000, (st_o, it_o)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"],
+                       f.get("y"), f.get("d"))
+    os.environ["ELLP_FORCE_REDO"] = "1"
+    try:
+        eng = E.Engine(E.ENGINE_PRIMAL if which == "primal" else E.ENGINE_DUAL, fp, E.default_opts(max_iter=100000))
+        try:
+            assert eng.counters()["certified_by_exact_lu_iteration"]
+            st, stats, msg = eng.run(100000)
+            eng.read_point()
+            c = eng.counters()
+        finally:
+            eng.close()
+    finally:
+        del os.environ["ELLP_FORCE_REDO"]
+    assert c["hybrid_redos"] == 1, c
+    assert st == E.OPTIMAL and int(stats.iters) == it_o, (st, stats.iters, it_o, msg)
+    np.testing.assert_array_equal(fp.B, ov.B)
+    np.testing.assert_array_equal(np.sort(fp.N[:fp.nN]), np.sort(ov.N[:ov.nN]))
+    np.testing.assert_allclose(fp.x, ov.x, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.x).max()))
+    if which == "dual":
+        np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.y).max()))
+        np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.d).max()))
