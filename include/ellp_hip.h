@@ -220,7 +220,10 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
  * final basis.  Between 129 and 1,024 rows a solve that ends Optimal on a point violating an invariant of the reference's loop by
  * more than EPS is repeated from the arrays the phase started with by the LU-per-iteration kernel alone; ellp_stats.iters is then
  * the repeated solve's count, and the engine keeps running on that kernel (no resident inverse: ellp_engine_dual_rephase returns
- * ELLP_ERR_ARG, as on any engine of that kind).
+ * ELLP_ERR_ARG, as on any engine of that kind).  Above 1,024 rows (up to 8,192) the same repetition runs every loop body on a
+ * fresh LU of the basis over all CUs (about 18 us x m per iteration), and is taken only when the iterations the phase needed,
+ * at that price, stay within ELLP_REDO_MAX_SECONDS (environment, default 900); otherwise the point is returned as it stands
+ * and counted (ELLP_TAP_STATE, "not certified").  The resident inverse follows that loop: the next phase runs fast again.
  *
  * ellp_engine_run(e, K) runs up to K loop bodies.  On the two-launch primal pipeline (m >= 384) a slice leaves the
  * ratio test of its last iteration to the next slice's first kernel; when the slice spends the caller's whole budget
