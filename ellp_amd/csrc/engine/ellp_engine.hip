@@ -2974,6 +2974,8 @@ struct ellp_engine {
     double *vs_val = nullptr;
     uint8_t *pos_hint = nullptr;
     int dual_maxviol = 0;  // ELLP_FLAG_DUAL_MAX_VIOLATION
+    int dual_bflip = 0;    // ELLP_FLAG_DUAL_BOUND_FLIPPING: the long-step ratio test (LU-per-iteration kernels only)
+    long long *bf_list = nullptr;  // ... the positions passed in an iteration (nN entries)
     bool se = false;       // ELLP_FLAG_PRIMAL_STEEPEST_EDGE (ellp_se.inc): three launches + one transposed GEMV per iteration
     double *se_gamma = nullptr, *se_rho = nullptr, *se_v = nullptr;
     double *se_vpart = nullptr;  // per row block of k_update2: its share of v = B^-T d (null: the separate transposed GEMV)
@@ -4370,6 +4372,13 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         }
     }
     e->dual_maxviol = (kind == ELLP_ENGINE_DUAL && (e->opts.flags & ELLP_FLAG_DUAL_MAX_VIOLATION)) ? 1 : 0;
+    e->dual_bflip = (kind == ELLP_ENGINE_DUAL && (e->opts.flags & ELLP_FLAG_DUAL_BOUND_FLIPPING)) ? 1 : 0;
+    if (e->dual_bflip && (e->opts.pipeline == 1 || e->opts.pipeline == 2 || e->pp_P > 1)) {
+        set_err(errbuf, errlen, "ELLP_FLAG_DUAL_BOUND_FLIPPING runs on the LU-per-iteration kernels (pipeline 0 or 3, up to 1,024 rows), "
+                                "not on the explicit-inverse pipelines 1 / 2");
+        ellp_engine_destroy(e);
+        return ELLP_ERR_ARG;
+    }
     if (kind == ELLP_ENGINE_DUAL) {
         bool box = true;
         for (int64_t i = 0; i < n_c && box; ++i) box = bound_kind[i] == ELLP_BOUND_TWOSIDED || bound_kind[i] == ELLP_BOUND_FIXED;
@@ -4414,7 +4423,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
         int64_t mid_auto = SMALL_MAX_M;
         if (const char *ev = getenv("ELLP_MID_AUTO_MAX")) mid_auto = atoll(ev);
         const bool fits = e->small_lds > 0 || e->mid_lds > 0;
-        const bool wanted = e->pp_P <= 1 && !e->se && (pl == 3 || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
+        const bool wanted = e->pp_P <= 1 && !e->se && (pl == 3 || e->dual_bflip || (pl == 0 && e->opts.refactor_period <= 0 && e->opts.btran_mode == 0 &&
                                                          e->opts.profile == 0 && (m <= SMALL_MAX_M || m <= mid_auto)));
         e->small = wanted && fits;
         e->mid = e->small && e->small_lds == 0;
@@ -4432,7 +4441,7 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
             if (ra == hipSuccess) ra = dmalloc(e, &e->A_Nt, (size_t)(ld * e->ldn));
             if (ra != hipSuccess) {
                 (void)hipGetLastError();
-                if (pl == 3) {
+                if (pl == 3 || e->dual_bflip) {
                     set_err(errbuf, errlen, "pipeline 3: no device memory for the factors of the persistent-workgroup loop");
                     ellp_engine_destroy(e);
                     return ELLP_ERR_DEVICE;
@@ -4452,6 +4461,20 @@ static ellp_status engine_create_impl(int kind, int64_t m, int64_t n, int64_t n_
                 (void)hipGetLastError();
                 e->small = false;  // the large engine handles it
             }
+        }
+    }
+    if (e->dual_bflip) {
+        // the long-step ratio test exists in k_small / k_mid only (a selection walk and one more solve with the iteration's LU)
+        if (!e->small && n_N > 0) {
+            set_err(errbuf, errlen, "ELLP_FLAG_DUAL_BOUND_FLIPPING: the LU-per-iteration kernels take up to 1,024 rows (this LP: %lld)", (long long)m);
+            ellp_engine_destroy(e);
+            return ELLP_ERR_ARG;
+        }
+        if (n_N > 0 && dmalloc(e, &e->bf_list, (size_t)n_N + 1) != hipSuccess) {
+            (void)hipGetLastError();
+            set_err(errbuf, errlen, "ELLP_FLAG_DUAL_BOUND_FLIPPING: no device memory for the list of passed positions");
+            ellp_engine_destroy(e);
+            return ELLP_ERR_DEVICE;
         }
     }
     // Certified hybrid (restated in oracle/ellp_oracle.c: hybrid_run), the default for 128 < m <= 1024: the
@@ -4606,6 +4629,10 @@ ellp_status ellp_engine_create_primal_phase1(int64_t m, int64_t n, const double 
 // The explicit-inverse engine is about to be used on an engine that has been running k_small: build
 // B^-1 from the current A_B and leave the small path for good.
 static ellp_status ensure_inverse(ellp_engine *e, char *errbuf, size_t errlen) {
+    if (e->dual_bflip) {  // the caller must be able to tell which rule runs: the explicit-inverse engine has no long-step ratio test
+        set_err(errbuf, errlen, "ELLP_FLAG_DUAL_BOUND_FLIPPING: this call needs the explicit-inverse engine, which has no long-step ratio test");
+        return ELLP_ERR_ARG;
+    }
     launch_flush(e);  // two-launch pipeline: B^-1 is complete only once the open iteration has been booked
     if (e->w_valid) {
         e->small = false;
@@ -4640,6 +4667,8 @@ static hipError_t launch_mid(ellp_engine *e, uint64_t iters, int resync) {
     a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
     a.stamps = e->small_stamps;
     a.maxviol = e->dual_maxviol;
+    a.bflip = e->dual_bflip;
+    a.flist = e->bf_list;
     a.resync = resync;
     a.b = e->b_dev;
     // the row-major copy of A_N the pricing pass reads: made afresh at every launch (anything may have
@@ -4674,6 +4703,8 @@ static ellp_status run_small(ellp_engine *e, uint64_t max_iters, char *errbuf, s
             a.trace = Trace{e->trace_obj, e->trace_it, e->trace_len};
             a.stamps = e->small_stamps;
             a.maxviol = e->dual_maxviol;
+            a.bflip = e->dual_bflip;
+            a.flist = e->bf_list;
             void *kargs[] = {&a};
             HIPCHK(hipLaunchKernel(small_kernel(e->kind, e->small_nt), dim3(1), dim3((unsigned)e->small_nt), kargs,
                                    e->small_lds, e->stream));

@@ -187,7 +187,8 @@ struct EngineOptions {
     int poll_interval = 0;
     int partial_segments = 0;  // ellp_opts.partial_segments (> 1: partial pricing, an opt-in extension)
     int pipeline = 0;  // ellp_opts.pipeline: 0 = chosen by size, 1 / 2 = launches per iteration, 3 = persistent small kernel
-    int flags = 0;     // ellp_opts.flags: ELLP_FLAG_DENSE_PRICING, ELLP_FLAG_DUAL_MAX_VIOLATION (an opt-in extension)
+    int flags = 0;     // ellp_opts.flags (include/ellp_hip.h): ELLP_FLAG_DENSE_PRICING, and the opt-in extensions ELLP_FLAG_DUAL_MAX_VIOLATION,
+                       // ELLP_FLAG_PRIMAL_STEEPEST_EDGE, ELLP_FLAG_DUAL_BOUND_FLIPPING; ELLP_FLAG_NO_CERTIFY
 };
 
 class PrimalSimplexSolver {  // src/solvers/primal/primal_simplex_solver.rs:15-93

@@ -62,6 +62,7 @@ enum { ELLP_NB_LOWER = 0, ELLP_NB_UPPER = 1, ELLP_NB_FREE = 2 };
 #define ELLP_FLAG_DUAL_MAX_VIOLATION 2 /* ellp_opts.flags */
 #define ELLP_FLAG_PRIMAL_STEEPEST_EDGE 4 /* ellp_opts.flags */
 #define ELLP_FLAG_NO_CERTIFY 8 /* ellp_opts.flags: the plain explicit-inverse engine where the default is the certified hybrid */
+#define ELLP_FLAG_DUAL_BOUND_FLIPPING 16 /* ellp_opts.flags */
 
 typedef struct ellp_opts {
     uint64_t max_iter;       /* self.max_iter (primal…:16, dual…:17); default 1000 (:21) */
@@ -109,7 +110,18 @@ typedef struct ellp_opts {
                                 40000) — the ratio test has no pivot-size safeguard, as the reference's has none
                                 bit 3 (ELLP_FLAG_NO_CERTIFY): with pipeline 0, the plain explicit-inverse engine above 128 rows — no
                                 pivot guard, no certificate behind a terminal status, no repeated solve (measurements, and the
-                                replay side of a sharded run's self-check: sharded engines run without them) */
+                                replay side of a sharded run's self-check: sharded engines run without them)
+                                bit 4 (ELLP_FLAG_DUAL_BOUND_FLIPPING), an EXTENSION (ellp's README.md:114-116),
+                                dual engines: the long-step ("bound flipping") ratio test — the dual step goes past the
+                                breakpoints of BOXED nonbasic variables, each moved to its other bound instead of entering, for as
+                                long as the leaving row's infeasibility |delta| minus the sum of |alpha_j| (ub_j - lb_j) over the
+                                passed breakpoints stays positive; breakpoints in (ratio, position) order; x_B follows the flips
+                                by one more solve with the iteration's LU.  Restated in the oracle first (eo_set_dual_rule bit
+                                0) and reproduced bit for bit.  Runs on the LU-per-iteration kernels only (pipeline 0 or 3, up
+                                to 1,024 rows; with this flag pipeline 0 selects them at every such size): more rows, pipeline
+                                1 / 2, partial pricing, or a call that needs the explicit-inverse engine (ellp_engine_step,
+                                ellp_engine_refactor, sharding) return ELLP_ERR_ARG.  Combines with bit 1.  Ignored by primal
+                                engines. */
 } ellp_opts;
 
 /* kernel ids for ellp_stats.kernel_ms / kernel_calls */

@@ -16,6 +16,7 @@ from test_gpu_small import assert_identical, flat
 
 pytestmark = pytest.mark.gpu
 MAXVIOL = 2
+BFLIP = 16  # ELLP_FLAG_DUAL_BOUND_FLIPPING (oracle: eo_set_dual_rule bit 0)
 
 
 def _E():
@@ -30,9 +31,10 @@ def _rule():
     eo.set_dual_rule(0)
 
 
-def _both_phases(prob, pipeline, exact, max_iter=400000):
+def _both_phases(prob, pipeline, exact, max_iter=400000, flags=MAXVIOL):
     """dual phase 1 and 2 at the seam, oracle (restated rule) against engine (the flag); returns the final objective"""
     E = _E()
+    eo.set_dual_rule((2 if flags & MAXVIOL else 0) | (1 if flags & BFLIP else 0))
     d1, err = eo.dual_phase1(prob)
     assert d1 is not None and not err
     ph, obj, total = d1, None, 0
@@ -41,7 +43,7 @@ def _both_phases(prob, pipeline, exact, max_iter=400000):
         ov = v.copy()
         st_o, it_o, err_o = eo.dual_solve_with_initial(ov, max_iter)
         fp = flat(v)
-        st_g, stats, err_g = E.dual_solve_with_initial(fp, E.default_opts(max_iter=max_iter, pipeline=pipeline, flags=MAXVIOL))
+        st_g, stats, err_g = E.dual_solve_with_initial(fp, E.default_opts(max_iter=max_iter, pipeline=pipeline, flags=flags))
         if exact:
             assert_identical((pipeline, phase), ov, st_o, it_o, err_o, fp, st_g, stats, err_g, "dual")
         else:
@@ -100,3 +102,83 @@ def test_closing_work_folded_into_the_next_pricing_launch():
         outs.append((st, int(stats.iters), fp.B.copy()))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
+
+
+# ---- the long-step ("bound flipping") ratio test, ELLP_FLAG_DUAL_BOUND_FLIPPING (ellp's README.md:114-116; oracle: bit 0) ----
+
+@pytest.mark.parametrize("flags", [BFLIP, BFLIP | MAXVIOL], ids=["flipping", "flipping+largest-violation"])
+@pytest.mark.parametrize("name", ["afiro", "adlittle", "blend"])
+def test_bound_flipping_bit_for_bit_on_the_persistent_kernel(name, flags):
+    """k_small (m <= 128): the walk over the breakpoints in (ratio, position) order, the flips of the passed boxed variables,
+    x_B after one more solve with the iteration's LU, the step from the violation AFTER the flips — status, iteration count,
+    index sets and every bit of x, y, d are the oracle's in both phases (phase 1 is a box problem: every variable can flip)"""
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == name)
+    prob = eo.Problem.from_fixture(read_mps(os.path.join(GOLDEN, ka["file"])))
+    obj, total = _both_phases(prob, 0 if name == "adlittle" else 3, True, flags=flags)  # with the flag, pipeline 0 selects the exact kernels too
+    assert abs(obj / ka["obj"] - 1.0) < 1e-6  # the rule changes the path, not the optimum
+
+
+@pytest.mark.parametrize("flags", [BFLIP, BFLIP | MAXVIOL], ids=["flipping", "flipping+largest-violation"])
+def test_bound_flipping_bit_for_bit_on_the_mid_kernel(flags):
+    """k_mid (ADLITTLE x 3, 168 rows; with the flag pipeline 0 runs the LU-per-iteration kernel alone, not the hybrid)"""
+    E = _E()
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == "adlittle")
+    base = blockdiag(read_mps(os.path.join(GOLDEN, ka["file"])), 3)
+    prob = eo.Problem.from_fixture(permuted_fixture(base, np.random.default_rng(3)))
+    obj, total = _both_phases(prob, 0, True, flags=flags)
+    assert abs(obj / (3 * ka["obj"]) - 1.0) < 1e-6
+    # fewer iterations than without the long step (the oracle: 752 / 313 against 1,034 / 344 under the plain ratio test)
+    assert total < (800 if flags == BFLIP else 330), total
+
+
+def test_bound_flipping_on_the_synthetic_family():
+    """150 x 380, both extensions, k_mid: bit for bit, and about half the iterations of the largest-violation rule alone
+    (3,839 there; SURVEY.md §8d's family has boxed variables in phase 1 only)"""
+    obj, total = _both_phases(eo.synth_problem(20260301, 150, 380), 3, True, flags=BFLIP | MAXVIOL)
+    assert abs(obj - (-192.0045391718814)) < 1e-8 * 192
+    assert total < 2500, total
+
+
+def test_bound_flipping_where_it_does_not_exist_is_an_error():
+    """the caller must be able to tell which rule ran: the explicit-inverse pipelines and LPs above 1,024 rows refuse the flag"""
+    E = _E()
+    from ellp_amd import synth
+    f = synth.dual_start_flat(9, 60, 100)
+    def fp_of(f):
+        return E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"],
+                             f["y"], f["d"])
+    for pipeline in (1, 2):
+        with pytest.raises(E.EllpHipError) as ei:
+            E.Engine(E.ENGINE_DUAL, fp_of(f), E.default_opts(max_iter=None, pipeline=pipeline, flags=BFLIP))
+        assert "BOUND_FLIPPING" in str(ei.value)
+    with pytest.raises(E.EllpHipError) as ei:
+        E.Engine(E.ENGINE_DUAL, fp_of(synth.dual_start_flat(9, 1100, 40)), E.default_opts(max_iter=None, flags=BFLIP))
+    assert "1,024" in str(ei.value)
+    eng = E.Engine(E.ENGINE_DUAL, fp_of(f), E.default_opts(max_iter=None, flags=BFLIP))
+    try:
+        with pytest.raises(E.EllpHipError):
+            eng.step(0)  # the stepped loop is the explicit-inverse engine's
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name,copies", [("blend", 1), ("adlittle", 3)])
+def test_bound_flipping_through_the_user_api(name, copies):
+    """DualSimplexSolver::new(None, flags).solve — both phases, the hand-off on the host (the LU-per-iteration engines keep no
+    inverse to re-phase from): the pinned optimum (tests/problems/mod.rs:661-673), a feasible point, no more iterations than the
+    plain ratio test under the same leaving rule"""
+    import ellp_amd
+    from helpers import fixture_violation
+    ka = next(p for p in known_answers()["netlib"] if p["name"] == name)
+    fx = read_mps(os.path.join(GOLDEN, ka["file"]))
+    if copies > 1:
+        fx = permuted_fixture(blockdiag(fx, copies), np.random.default_rng(3))
+    iters = {}
+    for flags in (MAXVIOL, MAXVIOL | BFLIP):
+        r = ellp_amd.DualSimplexSolver.new(400000, flags=flags).solve(ellp_amd.Problem.from_fixture(fx))
+        assert r.kind == ellp_amd.SolverResult.Optimal, (flags, r.kind)
+        assert abs(r.solution.obj() / (copies * ka["obj"]) - 1.0) < 1e-9
+        v = fixture_violation(fx, r.solution.x())
+        assert v[0] < 1e-8 and v[1] < 1e-8, v
+        iters[flags] = sum(r.iters)
+    assert iters[MAXVIOL | BFLIP] <= iters[MAXVIOL], iters  # the oracle: 47 / 47 (BLEND), 313 / 344 (ADLITTLE x 3)
