@@ -2237,7 +2237,7 @@ done:
  *   (dual…:45-50, dual_problem.rs:293-310) — measured both ways on ADLITTLE x 10 / x 18, the recomputed d fails those
  *   tests more often than the carried one (EO_HYBRID_RESYNC_YD=1 keeps the other variant for the record).  The primal keeps
  *   the carried x: its exact zeros at degenerate vertices are worth more than a recomputation
- *   that returns -3e-9 for them (measured: tools/hybrid_cpu.py, phase-1 objectives of -1e-8 and the reference's
+ *   that returns -3e-9 for them (measured: tests/campaign/hybrid_cpu.py, phase-1 objectives of -1e-8 and the reference's
  *   assert!(obj > -EPS) after a resync; none without).
  * Every decision that ends the solve is thus taken by the reference's arithmetic on a fresh factorisation
  * (primal…:173-189,289-292,404-406; dual…:241-246,281-284). */

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/blockdiag_cpu.py NAME COPIES ORDERS [seed] — CPU-only study behind tests/test_gpu_blockdiag.py:
+"""tests/campaign/blockdiag_cpu.py NAME COPIES ORDERS [seed] — CPU-only study behind tests/test_gpu_blockdiag.py:
 block-diagonal replications of a netlib LP in random variable / row orders, through the oracle's
 LU-per-iteration loops (the reference's arithmetic) and through its explicit-inverse loops (the large
 engine's algorithm on the host): how long the oracle takes and how often the explicit inverse ends
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""tools/blockdiag_large.py [copies orders] — replicated netlib LPs ABOVE 512 rows (ADLITTLE x 10: m = 560 by default), random
+"""tests/campaign/blockdiag_large.py [copies orders] — replicated netlib LPs ABOVE 512 rows (ADLITTLE x 10: m = 560 by default), random
 variable / constraint orders, both solvers at the seam: how the oracle ends each phase, how the default engine at that size
 (explicit inverse) ends it, and how the exact LU-per-iteration kernel does when ELLP_MID_AUTO_MAX=1024 makes it the choice —
 status, iterations, objective, seconds.  (tests/test_gpu_blockdiag.py pins the sizes up to 512 rows.)"""
 import json, os, sys, time, zlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from helpers import GOLDEN, blockdiag, known_answers, permuted_fixture, read_mps

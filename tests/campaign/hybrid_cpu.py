@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/hybrid_cpu.py NAME COPIES ORDERS [K] [resync] — CPU-only study of the certified hybrid (round 4, review item 1):
+"""tests/campaign/hybrid_cpu.py NAME COPIES ORDERS [K] [resync] — CPU-only study of the certified hybrid (round 4, review item 1):
 the oracle's explicit-inverse loop (the large engine's algorithm on the host) runs until it reports a terminal
 status; the oracle's LU-per-iteration loop (the reference's arithmetic) then runs up to K iterations from that basis.
 If its first iteration ends the same way the status is certified; if it pivots on, the explicit-inverse loop takes
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

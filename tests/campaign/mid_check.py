@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""tools/mid_check.py — quick look at the exact mid-size kernel: bits against the oracle and time per iteration"""
+"""tests/campaign/mid_check.py — quick look at the exact mid-size kernel: bits against the oracle and time per iteration"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import GOLDEN, blockdiag, known_answers, permuted_fixture, read_mps  # noqa: E402

@@ -8,7 +8,7 @@ bases: about one ADLITTLE x 6 dual run in fifteen).  Round 3 ran whole solves on
 since round 4 the default there is the certified hybrid (tests/test_gpu_hybrid.py: all 60 orders of each problem, on
 results), which calls this kernel for its certificates and as its fall-back — so its bit-equality with the oracle is
 what that design rests on, and it stays pinned here on a subset of the orders.  The plain explicit-inverse engine
-(pipeline = 1 / 2) ends differently from the oracle on 10-40 % of these orders (tools/blockdiag_cpu.py) and is measured
+(pipeline = 1 / 2) ends differently from the oracle on 10-40 % of these orders (tests/campaign/blockdiag_cpu.py) and is measured
 at the end of this file."""
 import os
 import zlib

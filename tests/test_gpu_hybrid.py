@@ -5,7 +5,7 @@ guarded iteration re-examined by the LU-per-iteration kernel from the same array
 Fixtures: block-diagonal replications of the reference's netlib LPs in random variable / constraint orders (the
 reference builds its problems by iterating HashMaps, tests/problems/mod.rs:657-674, so every order occurs).  Real,
 sparse, degenerate, ill-conditioned — the LPs on which the plain explicit-inverse loop ends wrongly on 10-40 % of the
-orders (tools/blockdiag_cpu.py).  Parity is on RESULTS, as the reference's own tests pin them: status,
+orders (tests/campaign/blockdiag_cpu.py).  Parity is on RESULTS, as the reference's own tests pin them: status,
 objective against the pinned optimum (tests/problems/mod.rs:661,667,673 x the number of copies, relative 1e-9) and
 feasibility of the point.  How the ORACLE (the reference's LU-per-iteration loop) ends on each of these orders is
 committed in tests/golden/blockdiag_orders.json / blockdiag_large.json (made by tests/campaign/blockdiag_large_golden.py;

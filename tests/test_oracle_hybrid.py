@@ -112,7 +112,7 @@ def test_a_guard_that_refuses_every_small_pivot_changes_nothing_but_the_path():
 
 def test_block_diagonal_orders_reach_the_pinned_optimum():
     """ADLITTLE x 3 and BLEND x 2, the first 10 orders of the GPU suite's (tests/test_gpu_hybrid.py): the hybrid reaches the pinned
-    optimum on every primal order — on BLEND x 2 the plain explicit-inverse loop loses some of them (tools/hybrid_cpu.py: 5 of
+    optimum on every primal order — on BLEND x 2 the plain explicit-inverse loop loses some of them (tests/campaign/hybrid_cpu.py: 5 of
     60: a pivot on a structural zero) — and on the dual wherever the reference's own loop does (tests/golden/blockdiag_orders.json)"""
     import json
     gold = json.load(open(os.path.join(GOLDEN, "blockdiag_orders.json")))
