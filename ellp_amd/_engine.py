@@ -17,6 +17,8 @@ STATUS_NAME = {0: "optimal", 1: "infeasible", 2: "unbounded", 3: "maxiter", -1: 
                -2: "err_singular", -3: "err_nan", -4: "err_device", -5: "err_arg", -6: "err_panic"}
 MAX_ITER_NONE = 2**64 - 1
 ENGINE_PRIMAL, ENGINE_DUAL = 0, 1
+# ellp_opts.flags (include/ellp_hip.h)
+FLAG_DENSE_PRICING, FLAG_DUAL_MAX_VIOLATION, FLAG_PRIMAL_STEEPEST_EDGE, FLAG_NO_CERTIFY, FLAG_DUAL_BOUND_FLIPPING = 1, 2, 4, 8, 16
 K_NAMES = ["price", "select", "ftran", "ratio", "update", "btran", "refactor", "dleave", "dprice",
            "dselect", "dupdate", "event_cost"]
 K_COUNT = 12

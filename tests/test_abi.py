@@ -39,6 +39,18 @@ def test_host_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"libellp_host.so does not export {n}"
 
 
+def test_flag_constants_are_the_headers():
+    """ellp_opts.flags: the Python constants are the #defines of include/ellp_hip.h, and every bit is documented at the field"""
+    text = open(os.path.join(ROOT, "include", "ellp_hip.h")).read()
+    defs = {n: int(v) for n, v in re.findall(r"#define\s+ELLP_FLAG_([A-Z_]+)\s+(\d+)", text)}
+    assert defs == {"DENSE_PRICING": _engine.FLAG_DENSE_PRICING, "DUAL_MAX_VIOLATION": _engine.FLAG_DUAL_MAX_VIOLATION,
+                    "PRIMAL_STEEPEST_EDGE": _engine.FLAG_PRIMAL_STEEPEST_EDGE, "NO_CERTIFY": _engine.FLAG_NO_CERTIFY,
+                    "DUAL_BOUND_FLIPPING": _engine.FLAG_DUAL_BOUND_FLIPPING}
+    assert sorted(defs.values()) == [1, 2, 4, 8, 16]
+    for n in defs:
+        assert text.count("ELLP_FLAG_" + n) >= 2, n  # the #define and the field's description
+
+
 def test_default_opts_reproduce_reference_defaults():
     o = _engine.default_opts()
     assert o.max_iter == 1000  # primal…:21, dual…:22
