@@ -182,3 +182,49 @@ def test_bound_flipping_through_the_user_api(name, copies):
         assert v[0] < 1e-8 and v[1] < 1e-8, v
         iters[flags] = sum(r.iters)
     assert iters[MAXVIOL | BFLIP] <= iters[MAXVIOL], iters  # the oracle: 47 / 47 (BLEND), 313 / 344 (ADLITTLE x 3)
+
+
+@pytest.mark.parametrize("flags", [BFLIP, BFLIP | MAXVIOL], ids=["flipping", "flipping+largest-violation"])
+def test_bound_flipping_random_lps_bit_for_bit(flags):
+    """300 random small LPs with every bound kind and integer data (exact ties between breakpoints, free and fixed variables,
+    the last-breakpoint case), 150 feasible box-bounded ones (phase 2 runs; every variable can flip) and 6 wide ones (30-80 rows,
+    thousands of columns: the walk's block-wide minima over many chunks): both dual phases on the exact kernel, every bit the
+    oracle's under the same rule"""
+    import test_gpu_random as R
+    E = _E()
+    eo.set_dual_rule((2 if flags & MAXVIOL else 0) | 1)
+    cases = [R.random_fixture(np.random.default_rng(s)) for s in range(21000, 21300)]
+    cases += [R.feasible_fixture(np.random.default_rng(s)) for s in range(27000, 27150)]
+    cases += [R.wide_fixture(np.random.default_rng(s)) for s in range(100, 106)]
+    ran = flipped_somewhere = 0
+    for k, fx in enumerate(cases):
+        prob = eo.Problem.from_fixture(fx)
+        d1, err = eo.dual_phase1(prob)
+        if d1 is None or err:
+            continue
+        ph = d1
+        for phase in (1, 2):
+            v = ph.view()
+            if v.m == 0:
+                break
+            ov = v.copy()
+            st_o, it_o, err_o = eo.dual_solve_with_initial(ov, 3000)
+            fp = flat(v)
+            st_g, stats, err_g = E.dual_solve_with_initial(fp, E.default_opts(max_iter=3000, pipeline=0, flags=flags))
+            assert_identical((k, phase), ov, st_o, it_o, err_o, fp, st_g, stats, err_g, "dual")
+            ran += 1
+            if phase == 1 and st_o == eo.OPTIMAL:
+                # the plain ratio test from the same arrays: a different iteration count means the walk passed breakpoints
+                eo.set_dual_rule(2 if flags & MAXVIOL else 0)
+                pv = v.copy()
+                _, it_p, _ = eo.dual_solve_with_initial(pv, 3000)
+                eo.set_dual_rule((2 if flags & MAXVIOL else 0) | 1)
+                flipped_somewhere += int(it_p != it_o)
+            if phase == 2 or st_o != eo.OPTIMAL:
+                break
+            ph.store_point(ov)
+            ph, e2 = eo.dual_phase2(ph)
+            if ph is None or e2:
+                break
+    assert ran > 300, ran
+    assert flipped_somewhere > 20, flipped_somewhere  # the long step really is taken in this population
