@@ -399,14 +399,16 @@ class Engine:
 
     def counters(self):
         """host-side maintenance counters (TAP_STATE tail)"""
-        v = self.tap(TAP_STATE, 29)
+        v = self.tap(TAP_STATE, 30)
         return dict(drift=v[12], drift_checks=int(v[13]), maint_requests=int(v[14]), refreshes=int(v[15]),
                     rebuilds=int(v[16]), resyncs=int(v[17]), last_refresh_residual=v[18], launches_per_iteration=int(v[19]),
                     rebuild_shortcuts=int(v[20]), t_setup_s=float(v[21]),
                     # certified hybrid (DESIGN.md §3.1c): is it on, guarded pivots handed to the exact kernel, terminal statuses
                     # examined, of those not confirmed, loop bodies run by the exact kernel, rebuilds after a hand-over
                     hybrid=(int(v[22]) == 1), certified_by_exact_lu_iteration=(int(v[22]) == 2), hybrid_guards=int(v[23]), hybrid_certs=int(v[24]), hybrid_disagreed=int(v[25]),
-                    hybrid_exact_iters=int(v[26]), hybrid_rebuilds=int(v[27]), hybrid_redos=int(v[28]))
+                    hybrid_exact_iters=int(v[26]), hybrid_rebuilds=int(v[27]), hybrid_redos=int(v[28]),
+                    # end points returned NOT certified (a redo above 1,024 rows ruled out by ELLP_REDO_MAX_SECONDS, a singular LU)
+                    hybrid_uncertified=int(v[29]))
 
     # ---- sharded / stepped driving (see ellp_amd/dist.py)
     def segment_doubles(self, world):

@@ -4965,7 +4965,7 @@ static hipError_t exact_workspace(ellp_engine *e) {
 }
 
 // "certify or redo" above 1,024 rows: after a redo every loop body runs on a fresh LU (ellp_engine::exact_large_only) — the
-// reference's LU-per-iteration loop on all CUs instead of in one workgroup: an LU (2 m launches) and four solves per iteration,
+// reference's LU-per-iteration loop on all CUs instead of in one workgroup: an LU (2 m launches) and two (primal) / three (dual) solves per iteration,
 // 20-40 ms at 1,000-2,000 rows; the explicit inverse is still updated along (a later phase goes back to the fast loop).
 static ellp_status run_exact_large(ellp_engine *e, uint64_t max_iters, char *errbuf, size_t errlen) {
     HIPCHK(exact_workspace(e));
@@ -5378,14 +5378,12 @@ ellp_status ellp_engine_run(ellp_engine *e, uint64_t max_iters, ellp_stats *stat
         if (getenv("ELLP_FORCE_REDO")) ok = false;  // tests: the redo path itself (snapshot, restore, the exact kernel from the start)
         const bool large = !e->hybrid;
         if (!ok && large) {
-            // Above 1,024 rows the exact loop costs an LU of 2 m launches and four solves of m steps per iteration (about
+            // Above 1,024 rows the exact loop costs an LU of 2 m launches and two or three solves of m steps per iteration (about
             // 18 us x m): the redo is taken when the iterations this phase needed, at that price, stay within
             // ELLP_REDO_MAX_SECONDS (default 900 — a 1,850-row phase of 3,000 iterations: 100 s; config 3's 600,000: never);
             // otherwise the point goes out as it is, counted as uncertified (ELLP_TAP_STATE).
-            static const double cap = [] {
-                const char *v = getenv("ELLP_REDO_MAX_SECONDS");
-                return v && v[0] ? atof(v) : 900.0;
-            }();
+            const char *capv = getenv("ELLP_REDO_MAX_SECONDS");  // read when it matters: once per phase end that fails the check
+            const double cap = capv && capv[0] ? atof(capv) : 900.0;
             const double est = (double)e->h_st->iters * 18e-6 * (double)e->m;
             if (est > cap) {
                 if (getenv("ELLP_HYBRID_DEBUG"))
@@ -5531,6 +5529,12 @@ int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap) {
                         dst[27] = (double)e->hy_rebuilds;
                         if (cap >= 29) {
                             dst[28] = (double)e->hy_redos;  // solves repeated by the exact kernel from the start of the phase
+                            if (cap >= 30) {
+                                // end points that went out NOT certified: a redo above 1,024 rows that would have cost more than
+                                // ELLP_REDO_MAX_SECONDS, an exactly singular LU in the certificate, no memory for its factors
+                                dst[29] = (double)e->hy_uncertified;
+                                return 30;
+                            }
                             return 29;
                         }
                         return 28;

@@ -385,9 +385,11 @@ enum { ELLP_TAP_U = 0, ELLP_TAP_R = 1, ELLP_TAP_D = 2, ELLP_TAP_BINV = 3, ELLP_T
                                                   serviced, Newton-Schulz refreshes, rebuilds, x_B resyncs, last
                                                   refresh residual, launches per primal iteration;
                                                   cap >= 22: + rebuilds settled by the permutation shortcut, setup seconds;
-                                                  cap >= 28 (29): + certified hybrid: on?, guarded pivots handed to the exact kernel,
+                                                  cap >= 28 (29, 30): + certified hybrid: on?, guarded pivots handed to the exact kernel,
                                                   terminal statuses examined, of those not confirmed, loop bodies run by the
-                                                  exact kernel, rebuilds of B^-1 after a hand-over (, solves repeated by the exact kernel) */ };
+                                                  exact kernel, rebuilds of B^-1 after a hand-over (, solves repeated by the exact
+                                                  kernel)(, end points returned NOT certified: a repetition above 1,024 rows that
+                                                  ELLP_REDO_MAX_SECONDS ruled out, a singular LU in the certificate) */ };
 int64_t ellp_engine_tap(ellp_engine *e, int what, double *dst, int64_t cap);
 
 /* One Newton-Schulz step W <- W + W (I - A_B W) on the resident inverse (two f64 GEMMs); this

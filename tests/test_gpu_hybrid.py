@@ -435,3 +435,30 @@ def test_a_redone_solve_above_1024_rows_follows_the_oracle(which):
     if which == "dual":
         np.testing.assert_allclose(fp.y, ov.y, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.y).max()))
         np.testing.assert_allclose(fp.d, ov.d, rtol=0, atol=1e-11 * (1.0 + np.abs(ov.d).max()))
+
+
+def test_a_redo_above_1024_rows_that_would_cost_too_much_is_not_taken_and_is_counted():
+    """ELLP_REDO_MAX_SECONDS: the repetition on fresh LUs costs about 18 us x m per iteration; when the iterations the phase
+    needed, at that price, exceed the cap the point goes out as it stands and ELLP_TAP_STATE counts it as not certified
+    (forced here: ELLP_FORCE_REDO makes the end point fail the check, a cap of 0 rules every repetition out)"""
+    E = _E()
+    from ellp_amd import synth
+    f = synth.dual_start_flat(9, 1100, 40)
+    fp = E.FlatProblem(f["m"], f["n"], f["n_c"], f["A"], f["c"], f["b"], f["kind"], f["lb"], f["ub"], f["x"], f["B"], f["N"], f["Nb"],
+                       f["y"], f["d"])
+    os.environ["ELLP_FORCE_REDO"] = "1"
+    os.environ["ELLP_REDO_MAX_SECONDS"] = "0"
+    try:
+        eng = E.Engine(E.ENGINE_DUAL, fp, E.default_opts(max_iter=100000))
+        try:
+            st, stats, msg = eng.run(100000)
+            eng.read_point()
+            c = eng.counters()
+        finally:
+            eng.close()
+    finally:
+        del os.environ["ELLP_FORCE_REDO"]
+        del os.environ["ELLP_REDO_MAX_SECONDS"]
+    assert st == E.OPTIMAL, (st, msg)
+    assert c["certified_by_exact_lu_iteration"] and c["hybrid_redos"] == 0 and c["hybrid_uncertified"] == 1, c
+    assert c["hybrid_certs"] >= 1  # the status itself was examined by an exact-LU iteration
