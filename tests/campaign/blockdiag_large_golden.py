@@ -28,6 +28,11 @@ CASES = [("adlittle", 10, 30), ("adlittle", 18, 30), ("blend", 14, 30)]
 # SMALL=1: the three problems of 148-336 rows, 60 orders each, into tests/golden/blockdiag_orders.json (seconds per solve)
 if os.environ.get("SMALL") == "1":
     CASES = [("adlittle", 3, 60), ("blend", 2, 60), ("adlittle", 6, 60)]
+# CASES=blend:25:20 SOLVERS=primal MODES=lu: other problems / a subset of the runs (above 1,024 rows the oracle's dual needs hours)
+if os.environ.get("CASES"):
+    CASES = [(c.split(":")[0], int(c.split(":")[1]), int(c.split(":")[2])) for c in os.environ["CASES"].split(",")]
+SOLVERS = os.environ.get("SOLVERS", "primal,dual").split(",")
+MODES = os.environ.get("MODES", "hybrid,lu").split(",")
 MAX_ITER = 2000000
 
 
@@ -90,7 +95,8 @@ def main():
             fx = permuted_fixture(base, rng)
             for dual in (False, True):
                 for mode in ("hybrid", "lu"):
-                    jobs.append((name, copies, t, fx, dual, mode))
+                    if ("dual" if dual else "primal") in SOLVERS and mode in MODES:
+                        jobs.append((name, copies, t, fx, dual, mode))
     jobs.sort(key=lambda j: (j[5] == "lu", j[1]))  # the cheap hybrid runs first
     path = os.path.join(GOLDEN, "blockdiag_orders.json" if os.environ.get("SMALL") == "1" else "blockdiag_large.json")
     res = json.load(open(path)) if os.path.exists(path) else {}
