@@ -462,3 +462,23 @@ def test_a_redo_above_1024_rows_that_would_cost_too_much_is_not_taken_and_is_cou
     assert st == E.OPTIMAL, (st, msg)
     assert c["certified_by_exact_lu_iteration"] and c["hybrid_redos"] == 0 and c["hybrid_uncertified"] == 1, c
     assert c["hybrid_certs"] >= 1  # the status itself was examined by an exact-LU iteration
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("trial", [2, 15])
+def test_a_redo_at_1850_rows_ends_with_the_oracles_iteration_counts(trial):
+    """BLEND x 25 (1,850 rows) through the user API, two of the orders whose first phase ends below -EPS on the fast loop
+    (profiles/r04_redo_above_1024_rows.json): the phase is repeated on fresh LUs (about 100 s) and the solve ends at the pinned
+    optimum with EXACTLY the iteration counts the oracle needs on that order (tests/golden/blockdiag_large.json, blendx25;
+    the oracle takes six minutes per order, which is why its outcome is a committed fixture).  ELLP_SLOW=1."""
+    import ellp_amd
+    gold = _golden()["blendx25"]["primal:lu"][str(trial)]
+    assert gold[0] == "p2" and gold[1] == eo.OPTIMAL
+    t, fx, want = [o for o in _orders("blend", 25, trial + 1)][-1]
+    assert t == trial
+    r = ellp_amd.PrimalSimplexSolver.new(400000).solve(ellp_amd.Problem.from_fixture(fx))
+    assert r.kind == ellp_amd.SolverResult.Optimal
+    assert abs(r.solution.obj() / want - 1.0) < 1e-9 and abs(r.solution.obj() / gold[2] - 1.0) < 1e-12
+    assert list(r.iters) == gold[3], (list(r.iters), gold[3])
+    v = fixture_violation(fx, r.solution.x())
+    assert v[0] < 1e-8 and v[1] < 1e-8, v
